@@ -1,0 +1,244 @@
+/*
+ * sai2b.h — C ABI of the batched operational-space controller for MI355X.
+ *
+ * This is the drop-in boundary for the hot path
+ *     RobotController::updateControllerTaskModels()   (reference src/RobotController.cpp:53-60)
+ *     RobotController::computeControlTorques()        (reference src/RobotController.cpp:62-74)
+ * and the task objects they drive (MotionForceTask, SingularityHandler, JointTask).
+ * The reference has no C ABI (it is a static C++ library, CMakeLists.txt:70); the entry points
+ * below are what a C++ adapter inside sai2-primitives would bind, and each one
+ * cites the reference member function it replaces.
+ *
+ * Conventions
+ *   - all numeric data is IEEE double
+ *   - batched arrays are SoA, batch-minor:  a[c * B + b]  = component c of robot b  ("[C][B]")
+ *   - matrices inside a component index are row-major (R[3*i+j], N[7*i+j], ...)
+ *   - a ctx owns every device buffer; callers copy in/out with sai2b_set_ / sai2b_get_, or write
+ *     device-resident data straight into the ctx buffers returned by sai2b_device_buffer()
+ *   - every function returns 0 on success, nonzero on error; sai2b_last_error() has the text.
+ *     Argument errors correspond to the reference's std::invalid_argument throws.
+ */
+#ifndef SAI2B_H_
+#define SAI2B_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAI2B_DOF 7		  /* this build is specialised for 7-DOF serial revolute chains */
+#define SAI2B_MAX_TASKS 4 /* tasks in one controller hierarchy */
+#define SAI2B_SH_HISTORY 200 /* SingularityHandler.cpp:16 BUFFER_SIZE */
+
+/* reference src/tasks/TemplateTask.h:19-23 */
+enum sai2b_task_type {
+	SAI2B_UNDEFINED = 0,
+	SAI2B_JOINT_TASK = 1,
+	SAI2B_MOTION_FORCE_TASK = 2
+};
+
+/* reference src/helper_modules/Sai2PrimitivesCommonDefinitions.h:9-15 */
+enum sai2b_decoupling {
+	SAI2B_FULL_DYNAMIC_DECOUPLING = 0,
+	SAI2B_BOUNDED_INERTIA_ESTIMATES = 1,
+	SAI2B_IMPEDANCE = 2
+};
+
+/* error codes */
+enum sai2b_status {
+	SAI2B_OK = 0,
+	SAI2B_INVALID_ARGUMENT = 1, /* reference: std::invalid_argument */
+	SAI2B_RUNTIME_ERROR = 2,	/* HIP failure */
+	SAI2B_UNSUPPORTED = 3
+};
+
+/*
+ * Rigid-body model of a fixed-base serial chain with SAI2B_DOF revolute joints about the local z
+ * axis (the subset of sai2-model the path needs: reference call sites SURVEY §8(c)).
+ * Joint i connects link i-1 (parent) to link i; link -1 is the world/base.
+ * Fixed children (e.g. the Panda "end-effector" body, panda_arm.urdf:105-116,179-183) must be merged
+ * into their parent's inertial parameters with sai2b_model_merge_fixed_body().
+ */
+typedef struct sai2b_robot_model {
+	int dof;									   /* must equal SAI2B_DOF */
+	double joint_xyz[SAI2B_DOF][3];				   /* URDF <origin xyz>, in parent link frame */
+	double joint_rpy[SAI2B_DOF][3];				   /* URDF <origin rpy>  (R = Rz(y) Ry(p) Rx(r)) */
+	double link_mass[SAI2B_DOF];				   /* child link of joint i */
+	double link_com[SAI2B_DOF][3];				   /* COM in link frame */
+	double link_inertia[SAI2B_DOF][6];			   /* ixx iyy izz ixy ixz iyz at the COM, link axes */
+	double q_lower[SAI2B_DOF], q_upper[SAI2B_DOF]; /* joint limits (SingularityHandler.cpp:43-51) */
+	double effort[SAI2B_DOF];
+	double gravity[3]; /* world gravity used by jointGravityVector (RobotController.cpp:71) */
+} sai2b_robot_model;
+
+/*
+ * One task of the hierarchy. Field defaults are filled by sai2b_default_joint_task() /
+ * sai2b_default_motion_force_task() and mirror JointTask.h:31-45, MotionForceTask.h:40-75,
+ * MotionForceTask.cpp:197 and SingularityHandler.cpp:10-20. Everything here is batch-uniform.
+ */
+typedef struct sai2b_task_config {
+	int type; /* enum sai2b_task_type */
+	char name[64];
+	double loop_timestep;
+	int dynamic_decoupling_type; /* enum sai2b_decoupling */
+	double bie_threshold;
+
+	/* ---- JointTask (JointTask.cpp:14-89) ---- */
+	int task_dof;								  /* rows of the selection matrix (SAI2B_DOF if full) */
+	double joint_selection[SAI2B_DOF * SAI2B_DOF]; /* row-major task_dof x SAI2B_DOF */
+	double kp[SAI2B_DOF], kv[SAI2B_DOF], ki[SAI2B_DOF];
+	int use_velocity_saturation; /* shared flag name for both task types */
+	double saturation_velocity[SAI2B_DOF];
+
+	/* ---- MotionForceTask (MotionForceTask.cpp:16-202) ---- */
+	int link;						/* 0-based moving link the compliant frame is attached to */
+	double frame_pos[3];			/* compliant frame in link frame: translation */
+	double frame_rot[9];			/*                               rotation (row-major) */
+	double partial_projection[36];	/* _partial_task_projection, blkdiag(P_pos, P_ori) */
+	int pos_range, ori_range;		/* ranks of the two 3x3 blocks (MotionForceTask.cpp:151-152) */
+	int parametrization_in_compliant_frame;
+	double kp_pos[3], kv_pos[3], ki_pos[3];
+	double kp_ori[3], kv_ori[3], ki_ori[3];
+	double kp_force[3], kv_force[3], ki_force[3];
+	double kp_moment[3], kv_moment[3], ki_moment[3];
+	double kff_force, kff_moment;
+	double max_force_feedback, max_moment_feedback;
+	int closed_loop_force, closed_loop_moment;
+	int force_space_dimension, moment_space_dimension;
+	double force_axis[3], moment_axis[3];
+	double linear_saturation_velocity, angular_saturation_velocity;
+	double sensor_rot[9], sensor_pos[3]; /* _T_control_to_sensor (MotionForceTask.cpp:793-803) */
+
+	/* ---- SingularityHandler (SingularityHandler.cpp:10-73, MotionForceTask.cpp:197) ---- */
+	double s_min, s_max, s_abs_tol;
+	double type_1_tol, type_2_torque_ratio, type_2_angle_threshold, perturb_step_size;
+	int sh_buffer_size;
+	double kp_type_1, kv_type_1, kv_type_2;
+	int enforce_type_1_strategy, enforce_handling_strategy;
+} sai2b_task_config;
+
+typedef struct sai2b_ctx sai2b_ctx;
+
+/* ------------------------------------------------------------------ model / config helpers
+ * (host-only, no GPU needed) */
+
+/* Panda arm constants (examples/15-haptic_control_impedance_type/panda_arm.urdf:4-184), with the
+ * fixed "end-effector" body merged into link 7. */
+int sai2b_panda_model(sai2b_robot_model* model);
+
+/* Merge a fixed child body into link `link` (what RBDL does for URDF fixed joints). */
+int sai2b_model_merge_fixed_body(sai2b_robot_model* model, int link, const double xyz[3],
+								 const double rpy[3], double mass, const double com[3],
+								 const double inertia[6]);
+
+/* JointTask::JointTask + initialSetup defaults (JointTask.cpp:14-89, JointTask.h:31-45).
+ * selection == NULL -> full joint task; else row-major task_dof x SAI2B_DOF, must be full row rank
+ * (JointTask.cpp:34-39). */
+int sai2b_default_joint_task(sai2b_task_config* cfg, const char* name, int task_dof,
+							 const double* selection);
+
+/* MotionForceTask::MotionForceTask + initialSetup defaults (MotionForceTask.cpp:16-202).
+ * n_trans/n_rot < 0 -> full 6-DOF task (first ctor); otherwise the partial-task ctor with the given
+ * controlled directions (row-major n x 3). frame_rot may be NULL (identity). */
+int sai2b_default_motion_force_task(sai2b_task_config* cfg, const char* name, int link,
+									const double frame_pos[3], const double* frame_rot,
+									int n_trans, const double* dirs_trans, int n_rot,
+									const double* dirs_rot);
+
+/* RobotController ctor checks (RobotController.cpp:8-51): at least one task, same loop timestep,
+ * unique names, nothing after a full joint task. Returns SAI2B_INVALID_ARGUMENT with `msg` filled. */
+int sai2b_validate_tasks(const sai2b_task_config* tasks, int n_tasks, char* msg, int msg_len);
+
+/* ------------------------------------------------------------------ controller (needs a GPU) */
+
+/* RobotController::RobotController (RobotController.cpp:8-51) for `batch` robot instances on HIP
+ * device `device`. Validates like the reference; allocates all device buffers; goals are
+ * initialised as reInitializeTask() does once a state has been set. Returns NULL on failure
+ * (see sai2b_last_error(NULL)). */
+sai2b_ctx* sai2b_create(const sai2b_robot_model* model, const sai2b_task_config* tasks, int n_tasks,
+						int batch, int device);
+void sai2b_destroy(sai2b_ctx* ctx);
+const char* sai2b_last_error(const sai2b_ctx* ctx);
+
+int sai2b_batch(const sai2b_ctx* ctx);
+int sai2b_num_tasks(const sai2b_ctx* ctx);
+
+/* Re-configure batch-uniform task parameters (gains, decoupling, force-space parametrisation,
+ * flags) after creation — the reference's setters (MotionForceTask.h:272-328,576-623,669-753,
+ * JointTask.h:234-259,360-384). Structural fields (type, task_dof, selection, link, projection)
+ * must not change. */
+int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_task_config* cfg);
+
+/* RobotController::enableGravityCompensation (RobotController.h:31-33) */
+int sai2b_enable_gravity_compensation(sai2b_ctx* ctx, int enable);
+
+/* Sai2Model::setQ / setDq + updateModel (examples/05-using_robot_controller.cpp:143-145).
+ * q, dq: [7][B]. on_device != 0 -> the pointers are device memory. */
+int sai2b_set_state(sai2b_ctx* ctx, const double* q, const double* dq, int on_device);
+
+/* MotionForceTask::setGoalPosition/Orientation/LinearVelocity/AngularVelocity/
+ * LinearAcceleration/AngularAcceleration (MotionForceTask.h:211-247). Any pointer may be NULL
+ * (left unchanged). pos,v,w,a,alpha: [3][B]; rot: [9][B] row-major. */
+int sai2b_set_mft_goals(sai2b_ctx* ctx, int task, const double* pos, const double* rot,
+						const double* lin_vel, const double* ang_vel, const double* lin_acc,
+						const double* ang_acc, int on_device);
+/* MotionForceTask::setGoalForce / setGoalMoment (MotionForceTask.h:590-623): [3][B] each */
+int sai2b_set_mft_goal_wrench(sai2b_ctx* ctx, int task, const double* force, const double* moment,
+							  int on_device);
+/* MotionForceTask::updateSensedForceAndMoment (MotionForceTask.cpp:805-828): sensor-frame values,
+ * [3][B] each; resolved to the world frame with the current state when the tick runs. */
+int sai2b_set_mft_sensed_wrench(sai2b_ctx* ctx, int task, const double* force, const double* moment,
+								int on_device);
+/* JointTask::setGoalPosition/Velocity/Acceleration (JointTask.h:137-179): [task_dof][B] each */
+int sai2b_set_jt_goals(sai2b_ctx* ctx, int task, const double* q_goal, const double* dq_goal,
+					   const double* ddq_goal, int on_device);
+
+/* RobotController::reinitializeTasks (RobotController.cpp:76-80): goals <- current state,
+ * integrators and singularity history cleared. */
+int sai2b_reinitialize(sai2b_ctx* ctx);
+
+/* RobotController::updateControllerTaskModels (RobotController.cpp:53-60) */
+int sai2b_update_task_models(sai2b_ctx* ctx);
+/* RobotController::computeControlTorques (RobotController.cpp:62-74). tau: [7][B]; may be NULL
+ * (result stays in the ctx torque buffer). with_compensation == 0 reproduces the manual flow of
+ * examples 04/18 (no-argument computeTorques(), torques summed). */
+int sai2b_compute_control_torques(sai2b_ctx* ctx, double* tau, int on_device);
+int sai2b_compute_control_torques_ex(sai2b_ctx* ctx, double* tau, int on_device,
+									 int with_compensation);
+/* update_task_models + compute_control_torques for the current state in ONE fused launch: the
+ * batched hot path. Enqueued on the ctx stream; does not synchronise when tau == NULL. */
+int sai2b_tick(sai2b_ctx* ctx, double* tau, int on_device);
+/* wait for everything enqueued on the ctx stream */
+int sai2b_synchronize(sai2b_ctx* ctx);
+/* the hipStream_t the ctx launches on (as void*) */
+void* sai2b_stream(sai2b_ctx* ctx);
+
+/* Device-resident ctx buffers, for zero-copy producers/consumers. `which`: */
+enum sai2b_buffer {
+	SAI2B_BUF_Q = 0,	  /* [7][B]  */
+	SAI2B_BUF_DQ = 1,	  /* [7][B]  */
+	SAI2B_BUF_TAU = 2,	  /* [7][B]  */
+	SAI2B_BUF_GOALS = 3,  /* per task; MFT: [30][B] = pos3 rot9 v3 w3 a3 alpha3 f3 m3; JT: [3k][B] */
+	SAI2B_BUF_SENSED = 4, /* per MFT task: [6][B] sensor-frame force, moment */
+	SAI2B_BUF_STATE = 5	  /* per task persistent state, see DESIGN.md */
+};
+void* sai2b_device_buffer(sai2b_ctx* ctx, int which, int task);
+
+/* Optional per-robot outputs of the last tick (debug / observers such as
+ * POPCBilateralTeleoperation.cpp:81-92). Arrays are host pointers; any may be NULL. */
+/* TemplateTask::getTaskAndPreviousNullspace (TemplateTask.h:88): [49][B] */
+int sai2b_get_task_nullspace(sai2b_ctx* ctx, int task, double* N_total);
+/* per-task torque contribution of the last tick: [7][B] */
+int sai2b_get_task_torques(sai2b_ctx* ctx, int task, double* tau_task);
+/* MFT: singular values [6][B], blending alpha [B], split index (non-singular rank) [B] as doubles */
+int sai2b_get_mft_singularity(sai2b_ctx* ctx, int task, double* sigma, double* alpha,
+							  double* ns_rank);
+/* Sai2Model::M(): [49][B]; J of MFT `task` (JWorldFrame): [42][B]; position [3][B], rotation [9][B] */
+int sai2b_get_model(sai2b_ctx* ctx, int task, double* M, double* J, double* pos, double* rot);
+
+/* number of kernel launches and robots processed since creation (bench bookkeeping) */
+int sai2b_counters(const sai2b_ctx* ctx, long long* launches, long long* ticks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAI2B_H_ */

@@ -1,0 +1,16 @@
+"""Batched operational-space controller for MI355X (gfx950).
+
+Host-side mirror of the sai2-primitives RobotController / MotionForceTask / JointTask API over the
+C ABI of include/sai2b.h, whose implementation is hand-written HIP (csrc/). See DESIGN.md.
+"""
+from . import _abi, workloads  # noqa: F401
+from ._abi import (  # noqa: F401
+    BOUNDED_INERTIA_ESTIMATES,
+    DOF,
+    FULL_DYNAMIC_DECOUPLING,
+    IMPEDANCE,
+    JOINT_TASK,
+    MOTION_FORCE_TASK,
+    RobotModel,
+    TaskConfig,
+)

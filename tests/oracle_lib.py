@@ -1,0 +1,278 @@
+"""ctypes wrapper around oracle/libsai2_oracle.so — the CPU oracle (test infrastructure only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import sai2_primitives_perso_amd as pkg
+from sai2_primitives_perso_amd._abi import DOF, RobotModel, TaskConfig
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "libsai2_oracle.so")
+
+_lib = None
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    src = os.path.join(ORACLE_DIR, "sai2_oracle.c")
+    if not os.path.exists(ORACLE_LIB) or os.path.getmtime(ORACLE_LIB) < os.path.getmtime(src):
+        build_oracle()
+    L = C.CDLL(ORACLE_LIB)
+    P, vp, d, i = C.POINTER, C.c_void_p, C.c_double, C.c_int
+    dp = P(d)
+    L.oracle_panda_model.argtypes = [P(RobotModel)]
+    L.oracle_model_merge_fixed_body.argtypes = [P(RobotModel), i, dp, dp, d, dp, dp]
+    L.oracle_default_joint_task.argtypes = [P(TaskConfig), C.c_char_p, i, dp]
+    L.oracle_default_motion_force_task.argtypes = [P(TaskConfig), C.c_char_p, i, dp, dp, i, dp, i, dp]
+    L.oracle_create.argtypes = [P(RobotModel), P(TaskConfig), i, i]
+    L.oracle_create.restype = vp
+    L.oracle_destroy.argtypes = [vp]
+    L.oracle_destroy.restype = None
+    L.oracle_last_error.restype = C.c_char_p
+    L.oracle_set_threads.argtypes = [vp, i]
+    L.oracle_set_threads.restype = None
+    L.oracle_update_task_config.argtypes = [vp, i, P(TaskConfig)]
+    L.oracle_enable_gravity_compensation.argtypes = [vp, i]
+    L.oracle_set_state.argtypes = [vp, vp, vp]
+    L.oracle_set_mft_goals.argtypes = [vp, i] + [vp] * 6
+    L.oracle_set_mft_goal_wrench.argtypes = [vp, i, vp, vp]
+    L.oracle_set_mft_sensed_wrench.argtypes = [vp, i, vp, vp]
+    L.oracle_set_jt_goals.argtypes = [vp, i, vp, vp, vp]
+    L.oracle_reinitialize.argtypes = [vp]
+    L.oracle_update_task_models.argtypes = [vp]
+    L.oracle_compute_control_torques.argtypes = [vp, vp, i]
+    L.oracle_tick.argtypes = [vp, vp]
+    L.oracle_get_task_nullspace.argtypes = [vp, i, vp]
+    L.oracle_get_task_torques.argtypes = [vp, i, vp]
+    L.oracle_get_mft_singularity.argtypes = [vp, i, vp, vp, vp]
+    L.oracle_get_model.argtypes = [vp, i, vp, vp, vp, vp]
+    L.oracle_get_minv.argtypes = [vp, vp]
+    L.oracle_get_gravity.argtypes = [vp, vp]
+    L.oracle_get_mft_lambda.argtypes = [vp, i, vp, vp]
+    L.oracle_get_mft_sh_state.argtypes = [vp, i, vp, vp, vp]
+    L.oracle_get_jt_inertia.argtypes = [vp, i, vp, vp]
+    L.oracle_svd.argtypes = [i, i, vp, vp, vp, vp]
+    L.oracle_svd.restype = None
+    L.oracle_inverse.argtypes = [i, vp, vp]
+    L.oracle_range_basis.argtypes = [i, i, vp, d, vp]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _arr(a, shape):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    assert a.shape == tuple(shape), (a.shape, shape)
+    return a
+
+
+def panda_model():
+    m = RobotModel()
+    assert lib().oracle_panda_model(C.byref(m)) == 0
+    return m
+
+
+def joint_task(name=None, selection=None):
+    c = TaskConfig()
+    sel = None if selection is None else np.ascontiguousarray(selection, dtype=np.float64)
+    rc = lib().oracle_default_joint_task(
+        C.byref(c),
+        name.encode() if name else None,
+        0 if sel is None else sel.shape[0],
+        None if sel is None else sel.ctypes.data_as(C.POINTER(C.c_double)),
+    )
+    if rc:
+        raise ValueError(lib().oracle_last_error().decode())
+    return c
+
+
+def motion_force_task(name=None, link=pkg.workloads.EE_LINK, frame_pos=pkg.workloads.EE_FRAME_POS, frame_rot=None,
+                      partial=None):
+    c = TaskConfig()
+    dp = C.POINTER(C.c_double)
+    fp = np.ascontiguousarray(frame_pos, dtype=np.float64)
+    fr = None if frame_rot is None else np.ascontiguousarray(frame_rot, dtype=np.float64)
+    if partial is None:
+        nt, nr, dt, dr = -1, -1, None, None
+    else:
+        dt = np.ascontiguousarray(partial[0], dtype=np.float64).reshape(-1, 3)
+        dr = np.ascontiguousarray(partial[1], dtype=np.float64).reshape(-1, 3)
+        nt, nr = dt.shape[0], dr.shape[0]
+    rc = lib().oracle_default_motion_force_task(
+        C.byref(c),
+        name.encode() if name else None,
+        link,
+        fp.ctypes.data_as(dp),
+        None if fr is None else fr.ctypes.data_as(dp),
+        nt,
+        None if dt is None or nt == 0 else dt.ctypes.data_as(dp),
+        nr,
+        None if dr is None or nr == 0 else dr.ctypes.data_as(dp),
+    )
+    if rc:
+        raise ValueError(lib().oracle_last_error().decode())
+    return c
+
+
+def task_configs(tasks):
+    """workloads.make_inputs()['tasks'] -> list of TaskConfig built by the ORACLE's helpers"""
+    out = []
+    for t, (kind, prm) in enumerate(tasks):
+        if kind == "jt":
+            out.append(joint_task(f"joint_task_{t}", prm.get("selection")))
+        else:
+            out.append(motion_force_task(f"motion_force_task_{t}", partial=prm.get("partial")))
+    return out
+
+
+class Oracle:
+    """Batch driver over the per-robot CPU oracle; same method names as pkg.Controller."""
+
+    def __init__(self, model, tasks, batch, threads=1):
+        self.L = lib()
+        self.B = batch
+        self.tasks = list(tasks)
+        arr = (TaskConfig * len(tasks))(*tasks)
+        self.h = self.L.oracle_create(C.byref(model), arr, len(tasks), batch)
+        if not self.h:
+            raise ValueError(self.L.oracle_last_error().decode())
+        self.L.oracle_set_threads(self.h, threads)
+
+    def close(self):
+        if self.h:
+            self.L.oracle_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _k0(self, task):
+        return self.tasks[task].task_dof
+
+    def update_task_config(self, task, cfg):
+        rc = self.L.oracle_update_task_config(self.h, task, C.byref(cfg))
+        if rc:
+            raise ValueError(self.L.oracle_last_error().decode())
+        self.tasks[task] = cfg
+
+    def enable_gravity_compensation(self, on):
+        self.L.oracle_enable_gravity_compensation(self.h, int(on))
+
+    def set_state(self, q, dq):
+        q, dq = _arr(q, (DOF, self.B)), _arr(dq, (DOF, self.B))
+        self.L.oracle_set_state(self.h, _ptr(q), _ptr(dq))
+
+    def set_mft_goals(self, task, pos=None, rot=None, v=None, w=None, a=None, alpha=None):
+        B = self.B
+        args = [_arr(pos, (3, B)), _arr(rot, (9, B)), _arr(v, (3, B)), _arr(w, (3, B)), _arr(a, (3, B)),
+                _arr(alpha, (3, B))]
+        rc = self.L.oracle_set_mft_goals(self.h, task, *[_ptr(x) for x in args])
+        if rc:
+            raise ValueError(self.L.oracle_last_error().decode())
+
+    def set_mft_goal_wrench(self, task, f=None, m=None):
+        f, m = _arr(f, (3, self.B)), _arr(m, (3, self.B))
+        assert self.L.oracle_set_mft_goal_wrench(self.h, task, _ptr(f), _ptr(m)) == 0
+
+    def set_mft_sensed_wrench(self, task, f=None, m=None):
+        f, m = _arr(f, (3, self.B)), _arr(m, (3, self.B))
+        assert self.L.oracle_set_mft_sensed_wrench(self.h, task, _ptr(f), _ptr(m)) == 0
+
+    def set_jt_goals(self, task, q=None, dq=None, ddq=None):
+        k0 = self._k0(task)
+        q, dq, ddq = _arr(q, (k0, self.B)), _arr(dq, (k0, self.B)), _arr(ddq, (k0, self.B))
+        rc = self.L.oracle_set_jt_goals(self.h, task, _ptr(q), _ptr(dq), _ptr(ddq))
+        if rc:
+            raise ValueError(self.L.oracle_last_error().decode())
+
+    def reinitialize(self):
+        self.L.oracle_reinitialize(self.h)
+
+    def update_task_models(self):
+        self.L.oracle_update_task_models(self.h)
+
+    def compute_control_torques(self, with_compensation=True):
+        tau = np.empty((DOF, self.B))
+        self.L.oracle_compute_control_torques(self.h, _ptr(tau), int(with_compensation))
+        return tau
+
+    def tick(self, want_output=True):
+        tau = np.empty((DOF, self.B)) if want_output else None
+        self.L.oracle_tick(self.h, _ptr(tau))
+        return tau
+
+    def get_task_nullspace(self, task):
+        out = np.empty((49, self.B))
+        assert self.L.oracle_get_task_nullspace(self.h, task, _ptr(out)) == 0
+        return out
+
+    def get_task_torques(self, task):
+        out = np.empty((DOF, self.B))
+        assert self.L.oracle_get_task_torques(self.h, task, _ptr(out)) == 0
+        return out
+
+    def get_mft_singularity(self, task):
+        s, a, r = np.empty((6, self.B)), np.empty(self.B), np.empty(self.B)
+        assert self.L.oracle_get_mft_singularity(self.h, task, _ptr(s), _ptr(a), _ptr(r)) == 0
+        return s, a, r
+
+    def get_model(self, task=-1):
+        M = np.empty((49, self.B))
+        if task < 0:
+            assert self.L.oracle_get_model(self.h, -1, _ptr(M), None, None, None) == 0
+            return M
+        J, x, R = np.empty((42, self.B)), np.empty((3, self.B)), np.empty((9, self.B))
+        assert self.L.oracle_get_model(self.h, task, _ptr(M), _ptr(J), _ptr(x), _ptr(R)) == 0
+        return M, J, x, R
+
+    def get_minv(self):
+        out = np.empty((49, self.B))
+        self.L.oracle_get_minv(self.h, _ptr(out))
+        return out
+
+    def get_gravity(self):
+        out = np.empty((DOF, self.B))
+        self.L.oracle_get_gravity(self.h, _ptr(out))
+        return out
+
+    def get_mft_lambda(self, task):
+        a, b = np.empty((36, self.B)), np.empty((36, self.B))
+        assert self.L.oracle_get_mft_lambda(self.h, task, _ptr(a), _ptr(b)) == 0
+        return a, b
+
+    def get_mft_sh_state(self, task):
+        a, b, c = np.empty(self.B), np.empty(self.B), np.empty(self.B)
+        assert self.L.oracle_get_mft_sh_state(self.h, task, _ptr(a), _ptr(b), _ptr(c)) == 0
+        return a, b, c
+
+    def get_jt_inertia(self, task):
+        k0 = self._k0(task)
+        a, b = np.empty((k0 * k0, self.B)), np.empty((k0 * k0, self.B))
+        assert self.L.oracle_get_jt_inertia(self.h, task, _ptr(a), _ptr(b)) == 0
+        return a, b
+
+
+def load_inputs(ctrl, inp):
+    """Feed a workloads.make_inputs() dict to an Oracle or a pkg.Controller."""
+    ctrl.set_state(inp["q"], inp["dq"])
+    for t, (kind, _) in enumerate(inp["tasks"]):
+        if kind == "mft":
+            g = inp[f"mft{t}"]
+            ctrl.set_mft_goals(t, g["pos"], g["rot"], g["v"], g["w"], g["a"], g["alpha"])
+        else:
+            g = inp[f"jt{t}"]
+            ctrl.set_jt_goals(t, g["q"], g["dq"], g["ddq"])
