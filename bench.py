@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py — control-ticks/sec of the batched operational-space controller on MI355X.
+
+One "step" = one fused tick (Sai2Model::updateModel + RobotController::updateControllerTaskModels +
+computeControlTorques, reference src/RobotController.cpp:53-74) over one batch of synthetic robots.
+Workload at every N: BASELINE.json configs[2] — 65 536 batched 7-DOF Panda per GPU,
+MotionForceTask + nullspace JointTask (SURVEY.md §8(d) "C3"); N > 1 shards the batch with no
+collective on the data path (weak scaling, "C5" at N = 8).
+
+Inputs are resident in HBM before the timed region; the timed region is K launches bracketed by a
+barrier + device synchronize, MAX over ranks. Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+BYTES_PER_TICK = 528  # q 7 + dq 7 + MFT goals 24 + JT goals 21 + tau 7 doubles
+FLOP_PER_TICK = 11.4e3  # SURVEY.md §8(d), SVD iterations excluded
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6
+
+
+def cpu_baseline(inp, seconds=8.0):
+    """the CPU oracle (our FP64 restatement of the reference, -O2) timed on this host's cores on a
+    bounded sample of the same workload"""
+    import oracle_lib as ol
+
+    sample = 8192
+    sub = {"B": sample, "tasks": inp["tasks"], "q": np.ascontiguousarray(inp["q"][:, :sample]),
+           "dq": np.ascontiguousarray(inp["dq"][:, :sample])}
+    for t, (kind, _) in enumerate(inp["tasks"]):
+        key = f"{kind}{t}"
+        sub[key] = {k: np.ascontiguousarray(v[:, :sample]) for k, v in inp[key].items()}
+    cores = len(os.sched_getaffinity(0))
+    res = {}
+    for label, threads in (("single", 1), ("all", cores)):
+        o = ol.Oracle(ol.panda_model(), ol.task_configs(sub["tasks"]), sample, threads=threads)
+        ol.load_inputs(o, sub)
+        o.tick(want_output=False)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds / 2:
+            o.tick(want_output=False)
+            n += 1
+        res[label] = n * sample / (time.perf_counter() - t0)
+        o.close()
+    return {
+        "value": res["all"],
+        "unit": "control-ticks/sec",
+        "cores": cores,
+        "kind": "port",
+        "single_thread_value": res["single"],
+        "sample": f"first {sample} robots of the same workload, repeated ticks for ~{seconds / 2:.0f} s per leg "
+                  f"(1 thread, then OpenMP over {cores} threads); oracle/sai2_oracle.c, gcc -O2",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=65536, help="robots per GPU")
+    ap.add_argument("--config", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import sai2_primitives_perso_amd as pkg
+
+    B = args.batch
+    inp = pkg.workloads.make_inputs(args.config if args.config != 5 else 3, B=B, rank=rank)
+    ctrl = pkg.Controller(pkg.panda_model(), pkg.task_configs(inp["tasks"]), B, device=local_rank)
+    import oracle_lib as ol  # only for load_inputs (a plain setter loop) and the cpu_baseline leg
+
+    ol.load_inputs(ctrl, inp)  # H2D once: inputs are resident before the timed region
+    ctrl.synchronize()
+    stream = torch.cuda.ExternalStream(ctrl.stream(), device=torch.device("cuda", local_rank))
+
+    def barrier():
+        ctrl.synchronize()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        ctrl.tick(want_output=False)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        ctrl.tick(want_output=False)
+    ev1.record(stream)
+    ctrl.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the ctx stream
+    if distributed:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+        dist.barrier()
+
+    if rank == 0:
+        total_ticks = B * world * args.steps
+        value = total_ticks / elapsed
+        per_launch_bytes = BYTES_PER_TICK * B
+        achieved = per_launch_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "control-ticks/sec (node), 65k batched 7-DOF Panda, 2-task hierarchy",
+            "value": value,
+            "unit": "control-ticks/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"C{args.config}: {B} batched Panda per GPU, MotionForceTask(6) + nullspace JointTask, "
+                            "library defaults, OTG off (SURVEY.md §8(d))" if args.config in (3, 5) else f"C{args.config}",
+                "robots_per_gpu": B,
+                "global_batch": B * world,
+                "parallelism": f"batch-sharded x{world}, no collective",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "sai2b::tick_kernel<false>",
+                "kernel_ms": kernel_ms,
+                "fp64_vector_frac": (FLOP_PER_TICK * B / (kernel_ms * 1e-3)) / (FP64_VECTOR_PEAK_TFLOPS * 1e12),
+                "note": "algorithmic bytes = 528 B/tick x robots per launch; the path is FP64-VALU/latency bound "
+                        "(SURVEY.md §8(d)), so the FP64 fraction is reported beside the HBM fraction",
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(inp)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -224,7 +224,10 @@ enum sai2b_buffer {
 void* sai2b_device_buffer(sai2b_ctx* ctx, int which, int task);
 
 /* Optional per-robot outputs of the last tick (debug / observers such as
- * POPCBilateralTeleoperation.cpp:81-92). Arrays are host pointers; any may be NULL. */
+ * POPCBilateralTeleoperation.cpp:81-92). Introspection must be enabled BEFORE the tick whose values
+ * are wanted (it selects a kernel variant that also stores these arrays); the getters fail with
+ * SAI2B_INVALID_ARGUMENT otherwise. Arrays are host pointers; any may be NULL. */
+int sai2b_enable_introspection(sai2b_ctx* ctx, int enable);
 /* TemplateTask::getTaskAndPreviousNullspace (TemplateTask.h:88): [49][B] */
 int sai2b_get_task_nullspace(sai2b_ctx* ctx, int task, double* N_total);
 /* per-task torque contribution of the last tick: [7][B] */

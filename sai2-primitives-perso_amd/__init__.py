@@ -14,3 +14,14 @@ from ._abi import (  # noqa: F401
     RobotModel,
     TaskConfig,
 )
+from .controller import (  # noqa: F401,E402
+    BatchedRobotModel,
+    Controller,
+    JointTask,
+    MotionForceTask,
+    RobotController,
+    joint_task_config,
+    motion_force_task_config,
+    panda_model,
+    task_configs,
+)

@@ -164,6 +164,7 @@ EXPORTS = [
     "sai2b_synchronize",
     "sai2b_stream",
     "sai2b_device_buffer",
+    "sai2b_enable_introspection",
     "sai2b_get_task_nullspace",
     "sai2b_get_task_torques",
     "sai2b_get_mft_singularity",
@@ -218,6 +219,7 @@ def load_library():
     lib.sai2b_stream.restype = vp
     lib.sai2b_device_buffer.argtypes = [vp, _i, _i]
     lib.sai2b_device_buffer.restype = vp
+    lib.sai2b_enable_introspection.argtypes = [vp, _i]
     lib.sai2b_get_task_nullspace.argtypes = [vp, _i, vp]
     lib.sai2b_get_task_torques.argtypes = [vp, _i, vp]
     lib.sai2b_get_mft_singularity.argtypes = [vp, _i, vp, vp, vp]

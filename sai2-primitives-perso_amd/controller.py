@@ -1,0 +1,574 @@
+"""Host-side mirror of the reference's controller interface over the C ABI (include/sai2b.h).
+
+``Controller`` is the thin array-level binding (SoA numpy arrays or raw device pointers in, torques
+out). The classes ``BatchedRobotModel``, ``JointTask``, ``MotionForceTask`` and ``RobotController``
+keep the reference's names, argument meaning and error behaviour
+(reference src/RobotController.h:25-40, src/tasks/JointTask.h:56-384,
+src/tasks/MotionForceTask.h:96-753) but every vector/matrix is batched: shape ``[C, B]``
+(component-major, batch-minor). std::invalid_argument becomes ValueError; HIP failures RuntimeError.
+
+All numerical work happens in csrc/libsai2b.so (HIP, gfx950). There is no CPU fallback: creating a
+controller without the library or without a GPU raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import DOF, MOTION_FORCE_TASK, RobotModel, TaskConfig
+from .workloads import EE_FRAME_POS, EE_LINK
+
+
+def _check(lib, handle, rc):
+    if rc == _abi.OK:
+        return
+    msg = lib.sai2b_last_error(handle)
+    msg = msg.decode() if msg else "unknown error"
+    if rc == _abi.INVALID_ARGUMENT:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def panda_model():
+    """sai2b_panda_model(): Panda constants with the fixed end-effector body merged into link 7."""
+    lib = _abi.load_library()
+    m = RobotModel()
+    _check(lib, None, lib.sai2b_panda_model(C.byref(m)))
+    return m
+
+
+def joint_task_config(name=None, selection=None):
+    """sai2b_default_joint_task(): JointTask ctor + defaults (JointTask.cpp:14-89)."""
+    lib = _abi.load_library()
+    c = TaskConfig()
+    sel = None if selection is None else np.ascontiguousarray(selection, dtype=np.float64)
+    if sel is not None and (sel.ndim != 2 or sel.shape[1] != DOF):
+        raise ValueError("joint selection matrix size not consistent with robot dof in JointTask constructor\n")
+    rc = lib.sai2b_default_joint_task(C.byref(c), name.encode() if name else None, 0 if sel is None else sel.shape[0], _dp(sel))
+    _check(lib, None, rc)
+    return c
+
+
+def motion_force_task_config(name=None, link=EE_LINK, frame_pos=EE_FRAME_POS, frame_rot=None, partial=None):
+    """sai2b_default_motion_force_task(): MotionForceTask ctors + defaults (MotionForceTask.cpp:16-202).
+    partial = (translation directions [n,3], rotation directions [m,3]) selects the partial-task ctor."""
+    lib = _abi.load_library()
+    c = TaskConfig()
+    fp = np.ascontiguousarray(frame_pos, dtype=np.float64)
+    fr = None if frame_rot is None else np.ascontiguousarray(frame_rot, dtype=np.float64)
+    if partial is None:
+        nt, nr, dt, dr = -1, -1, None, None
+    else:
+        dt = np.ascontiguousarray(partial[0], dtype=np.float64).reshape(-1, 3)
+        dr = np.ascontiguousarray(partial[1], dtype=np.float64).reshape(-1, 3)
+        nt, nr = dt.shape[0], dr.shape[0]
+    rc = lib.sai2b_default_motion_force_task(
+        C.byref(c), name.encode() if name else None, link, _dp(fp), _dp(fr),
+        nt, _dp(dt) if nt and nt > 0 else None, nr, _dp(dr) if nr and nr > 0 else None,
+    )
+    _check(lib, None, rc)
+    return c
+
+
+def task_configs(tasks):
+    """workloads.make_inputs()['tasks'] -> list of TaskConfig built by the product's helpers"""
+    out = []
+    for t, (kind, prm) in enumerate(tasks):
+        if kind == "jt":
+            out.append(joint_task_config(f"joint_task_{t}", prm.get("selection")))
+        else:
+            out.append(motion_force_task_config(f"motion_force_task_{t}", partial=prm.get("partial")))
+    return out
+
+
+class Controller:
+    """Array-level binding of one sai2b_ctx (one GPU, one batch)."""
+
+    def __init__(self, model, tasks, batch, device=0, introspection=False):
+        self.lib = _abi.load_library()
+        self.B = int(batch)
+        self.tasks = list(tasks)
+        arr = (TaskConfig * len(self.tasks))(*self.tasks)
+        self.h = self.lib.sai2b_create(C.byref(model), arr, len(self.tasks), self.B, int(device))
+        if not self.h:
+            msg = self.lib.sai2b_last_error(None).decode()
+            if "hip" in msg.lower():
+                raise RuntimeError(msg)
+            raise ValueError(msg)
+        if introspection:
+            self.enable_introspection(True)
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sai2b_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _rc(self, rc):
+        _check(self.lib, self.h, rc)
+
+    def _in(self, a, rows):
+        """-> (pointer, on_device, keepalive) for a numpy array, a torch CUDA tensor, or None"""
+        if a is None:
+            return None, None
+        if hasattr(a, "data_ptr"):  # torch tensor
+            if not a.is_cuda or not a.is_contiguous() or tuple(a.shape) != (rows, self.B) or str(a.dtype) != "torch.float64":
+                raise ValueError(f"expected a contiguous float64 CUDA tensor of shape ({rows}, {self.B})")
+            return C.c_void_p(a.data_ptr()), a
+        arr = np.ascontiguousarray(a, dtype=np.float64)
+        if arr.shape != (rows, self.B):
+            raise ValueError(f"expected an array of shape ({rows}, {self.B}), got {arr.shape}")
+        return C.c_void_p(arr.ctypes.data), arr
+
+    @staticmethod
+    def _dev(*objs):
+        kinds = {hasattr(o, "data_ptr") for o in objs if o is not None}
+        if len(kinds) > 1:
+            raise ValueError("mixing host arrays and device tensors in one call")
+        return 1 if kinds == {True} else 0
+
+    # -- configuration
+    def update_task_config(self, task, cfg):
+        self._rc(self.lib.sai2b_update_task_config(self.h, task, C.byref(cfg)))
+        self.tasks[task] = cfg
+
+    def enable_gravity_compensation(self, on=True):
+        self._rc(self.lib.sai2b_enable_gravity_compensation(self.h, int(on)))
+
+    def enable_introspection(self, on=True):
+        self._rc(self.lib.sai2b_enable_introspection(self.h, int(on)))
+
+    # -- inputs
+    def set_state(self, q=None, dq=None):
+        pq, kq = self._in(q, DOF)
+        pd, kd = self._in(dq, DOF)
+        self._rc(self.lib.sai2b_set_state(self.h, pq, pd, self._dev(q, dq)))
+
+    def set_mft_goals(self, task, pos=None, rot=None, v=None, w=None, a=None, alpha=None):
+        objs = (pos, rot, v, w, a, alpha)
+        ins = [self._in(o, r) for o, r in zip(objs, (3, 9, 3, 3, 3, 3))]
+        self._rc(self.lib.sai2b_set_mft_goals(self.h, task, *[p for p, _ in ins], self._dev(*objs)))
+
+    def set_mft_goal_wrench(self, task, f=None, m=None):
+        ins = [self._in(f, 3), self._in(m, 3)]
+        self._rc(self.lib.sai2b_set_mft_goal_wrench(self.h, task, ins[0][0], ins[1][0], self._dev(f, m)))
+
+    def set_mft_sensed_wrench(self, task, f=None, m=None):
+        ins = [self._in(f, 3), self._in(m, 3)]
+        self._rc(self.lib.sai2b_set_mft_sensed_wrench(self.h, task, ins[0][0], ins[1][0], self._dev(f, m)))
+
+    def set_jt_goals(self, task, q=None, dq=None, ddq=None):
+        if not (0 <= task < len(self.tasks)):
+            raise ValueError("bad task index")
+        k0 = self.tasks[task].task_dof
+        ins = [self._in(o, k0) for o in (q, dq, ddq)]
+        self._rc(self.lib.sai2b_set_jt_goals(self.h, task, *[p for p, _ in ins], self._dev(q, dq, ddq)))
+
+    # -- the path
+    def reinitialize(self):
+        self._rc(self.lib.sai2b_reinitialize(self.h))
+
+    def update_task_models(self):
+        self._rc(self.lib.sai2b_update_task_models(self.h))
+
+    def compute_control_torques(self, with_compensation=True, out=None):
+        return self._torques(lambda p, dev: self.lib.sai2b_compute_control_torques_ex(self.h, p, dev, int(with_compensation)), out)
+
+    def tick(self, out=None, want_output=True):
+        """fused update_task_models + compute_control_torques; with want_output=False only enqueues"""
+        if not want_output:
+            self._rc(self.lib.sai2b_tick(self.h, None, 0))
+            return None
+        return self._torques(lambda p, dev: self.lib.sai2b_tick(self.h, p, dev), out)
+
+    def _torques(self, call, out):
+        if out is None:
+            out = np.empty((DOF, self.B))
+        p, keep = self._in(out, DOF)
+        if not hasattr(out, "data_ptr") and keep is not out:
+            raise ValueError("out must be a C-contiguous float64 array")
+        self._rc(call(p, self._dev(out)))
+        return out
+
+    def synchronize(self):
+        self._rc(self.lib.sai2b_synchronize(self.h))
+
+    def stream(self):
+        return self.lib.sai2b_stream(self.h)
+
+    def device_buffer(self, which, task=-1):
+        return self.lib.sai2b_device_buffer(self.h, which, task)
+
+    def counters(self):
+        a, b = C.c_longlong(), C.c_longlong()
+        self.lib.sai2b_counters(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    # -- introspection of the last tick
+    def get_task_nullspace(self, task):
+        out = np.empty((DOF * DOF, self.B))
+        self._rc(self.lib.sai2b_get_task_nullspace(self.h, task, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def get_task_torques(self, task):
+        out = np.empty((DOF, self.B))
+        self._rc(self.lib.sai2b_get_task_torques(self.h, task, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def get_mft_singularity(self, task):
+        s, a, r = np.empty((6, self.B)), np.empty(self.B), np.empty(self.B)
+        self._rc(self.lib.sai2b_get_mft_singularity(self.h, task, *[C.c_void_p(x.ctypes.data) for x in (s, a, r)]))
+        return s, a, r
+
+    def get_model(self, task=-1):
+        M = np.empty((DOF * DOF, self.B))
+        if task < 0:
+            self._rc(self.lib.sai2b_get_model(self.h, -1, C.c_void_p(M.ctypes.data), None, None, None))
+            return M
+        J, x, R = np.empty((6 * DOF, self.B)), np.empty((3, self.B)), np.empty((9, self.B))
+        self._rc(self.lib.sai2b_get_model(self.h, task, *[C.c_void_p(a.ctypes.data) for a in (M, J, x, R)]))
+        return M, J, x, R
+
+
+# --------------------------------------------------------------------------------------------------
+# reference-named, batch-aware facade
+# --------------------------------------------------------------------------------------------------
+class BatchedRobotModel:
+    """Stands where the reference takes ``std::shared_ptr<Sai2Model::Sai2Model>``: the constant
+    model plus the batch size and the device; q/dq are set on it as on the reference's model
+    (examples/05-using_robot_controller.cpp:143-145)."""
+
+    def __init__(self, batch, model=None, device=0):
+        self.batch = int(batch)
+        self.device = int(device)
+        self.model = model if model is not None else panda_model()
+        self._q = np.zeros((DOF, self.batch))
+        self._dq = np.zeros((DOF, self.batch))
+        self._controller = None
+
+    def dof(self):
+        return DOF
+
+    def setQ(self, q):
+        self._q = q
+        self._push()
+
+    def setDq(self, dq):
+        self._dq = dq
+        self._push()
+
+    def q(self):
+        return self._q
+
+    def dq(self):
+        return self._dq
+
+    def updateModel(self):
+        """kept for call-order compatibility: the model update is fused into the tick kernel"""
+        self._push()
+
+    def _push(self):
+        if self._controller is not None:
+            self._controller._ctrl.set_state(self._q, self._dq)
+
+
+class _TaskBase:
+    def __init__(self, robot, cfg):
+        self._robot = robot
+        self._cfg = cfg
+        self._owner = None  # (RobotController, index) once attached
+        self._pending = {}
+
+    # TemplateTask accessors (reference src/tasks/TemplateTask.h:95-115)
+    def getTaskName(self):
+        return self._cfg.name.decode()
+
+    def getTaskType(self):
+        return self._cfg.type
+
+    def getLoopTimestep(self):
+        return self._cfg.loop_timestep
+
+    def getConstRobotModel(self):
+        return self._robot
+
+    def setDynamicDecouplingType(self, t):
+        self._cfg.dynamic_decoupling_type = int(t)
+        self._sync_cfg()
+
+    def setBoundedInertiaEstimateThreshold(self, thr):
+        self._cfg.bie_threshold = max(float(thr), 0.0)  # JointTask.h:369-375
+        self._sync_cfg()
+
+    def _sync_cfg(self):
+        if self._owner:
+            rc, idx = self._owner
+            rc._ctrl.update_task_config(idx, self._cfg)
+
+    def _goal(self, key, value, rows):
+        B = self._robot.batch
+        if not hasattr(value, "data_ptr"):
+            value = np.ascontiguousarray(value, dtype=np.float64)
+            if value.shape != (rows, B):
+                raise ValueError(f"goal must have shape ({rows}, {B})")
+        self._pending[key] = value
+        self._flush()
+
+    def getTaskAndPreviousNullspace(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_task_nullspace(idx)
+
+    def _require_owner(self):
+        if not self._owner:
+            raise ValueError("task is not attached to a RobotController")
+        return self._owner
+
+
+class JointTask(_TaskBase):
+    """reference src/tasks/JointTask.h:56-75 (ctors), :137-179 (goals), :234-259 (gains)"""
+
+    def __init__(self, robot, joint_selection_matrix=None, task_name="joint_task", loop_timestep=0.001):
+        cfg = joint_task_config(task_name, joint_selection_matrix)
+        cfg.loop_timestep = loop_timestep
+        super().__init__(robot, cfg)
+
+    def isFullJointTask(self):
+        return self._cfg.task_dof == DOF
+
+    def setGoalPosition(self, q):
+        self._goal("q", q, self._cfg.task_dof)
+
+    def setGoalVelocity(self, dq):
+        self._goal("dq", dq, self._cfg.task_dof)
+
+    def setGoalAcceleration(self, ddq):
+        self._goal("ddq", ddq, self._cfg.task_dof)
+
+    def setGains(self, kp, kv, ki=0.0):
+        kp, kv, ki = (np.broadcast_to(np.asarray(x, dtype=float), (self._cfg.task_dof,)) for x in (kp, kv, ki))
+        if kp.min() < 0 or kv.min() < 0 or ki.min() < 0:
+            raise ValueError("gains must be positive or zero in JointTask::setGains\n")
+        for i in range(self._cfg.task_dof):
+            self._cfg.kp[i], self._cfg.kv[i], self._cfg.ki[i] = kp[i], kv[i], ki[i]
+        self._sync_cfg()
+
+    def enableVelocitySaturation(self, saturation_velocity):
+        v = np.broadcast_to(np.asarray(saturation_velocity, dtype=float), (self._cfg.task_dof,))
+        if v.min() <= 0:
+            raise ValueError("saturation velocity must be positive in JointTask::enableVelocitySaturation\n")
+        self._cfg.use_velocity_saturation = 1
+        for i in range(self._cfg.task_dof):
+            self._cfg.saturation_velocity[i] = v[i]
+        self._sync_cfg()
+
+    def disableVelocitySaturation(self):
+        self._cfg.use_velocity_saturation = 0
+        self._sync_cfg()
+
+    def disableInternalOtg(self):
+        """the internal OTG is not part of this path: desired state = goal state"""
+
+    def _flush(self):
+        if self._owner and self._pending:
+            rc, idx = self._owner
+            rc._ctrl.set_jt_goals(idx, self._pending.get("q"), self._pending.get("dq"), self._pending.get("ddq"))
+            self._pending = {}
+
+
+class MotionForceTask(_TaskBase):
+    """reference src/tasks/MotionForceTask.h:96-110 (ctors), :211-247 (goals), :272-328 (gains),
+    :576-623 (force space)"""
+
+    def __init__(self, robot, link=EE_LINK, compliant_frame_pos=EE_FRAME_POS, compliant_frame_rot=None,
+                 controlled_directions_translation=None, controlled_directions_rotation=None,
+                 task_name=None, is_force_motion_parametrization_in_compliant_frame=False, loop_timestep=0.001):
+        partial = None
+        if controlled_directions_translation is not None or controlled_directions_rotation is not None:
+            partial = (
+                np.zeros((0, 3)) if controlled_directions_translation is None else controlled_directions_translation,
+                np.zeros((0, 3)) if controlled_directions_rotation is None else controlled_directions_rotation,
+            )
+        cfg = motion_force_task_config(task_name, link, compliant_frame_pos, compliant_frame_rot, partial)
+        cfg.parametrization_in_compliant_frame = int(is_force_motion_parametrization_in_compliant_frame)
+        cfg.loop_timestep = loop_timestep
+        super().__init__(robot, cfg)
+
+    def setGoalPosition(self, x):
+        self._goal("pos", x, 3)
+
+    def setGoalOrientation(self, R):
+        self._goal("rot", R, 9)
+
+    def setGoalLinearVelocity(self, v):
+        self._goal("v", v, 3)
+
+    def setGoalAngularVelocity(self, w):
+        self._goal("w", w, 3)
+
+    def setGoalLinearAcceleration(self, a):
+        self._goal("a", a, 3)
+
+    def setGoalAngularAcceleration(self, a):
+        self._goal("alpha", a, 3)
+
+    def setGoalForce(self, f):
+        self._goal("f", f, 3)
+
+    def setGoalMoment(self, m):
+        self._goal("m", m, 3)
+
+    def updateSensedForceAndMoment(self, f, m):
+        self._goal("sf", f, 3)
+        self._goal("sm", m, 3)
+
+    def _set3(self, names, values, where):
+        vals = [np.broadcast_to(np.asarray(v, dtype=float), (3,)) for v in values]
+        if min(v.min() for v in vals) < 0:
+            raise ValueError(f"all gains should be positive or zero in MotionForceTask::{where}\n")
+        for n, v in zip(names, vals):
+            for i in range(3):
+                getattr(self._cfg, n)[i] = v[i]
+        self._sync_cfg()
+
+    def setPosControlGains(self, kp, kv, ki=0.0):
+        self._set3(("kp_pos", "kv_pos", "ki_pos"), (kp, kv, ki), "setPosControlGains")
+
+    def setOriControlGains(self, kp, kv, ki=0.0):
+        self._set3(("kp_ori", "kv_ori", "ki_ori"), (kp, kv, ki), "setOriControlGains")
+
+    def setForceControlGains(self, kp, kv, ki):
+        self._set3(("kp_force", "kv_force", "ki_force"), (kp, kv, ki), "setForceControlGains")
+
+    def setMomentControlGains(self, kp, kv, ki):
+        self._set3(("kp_moment", "kv_moment", "ki_moment"), (kp, kv, ki), "setMomentControlGains")
+
+    def parametrizeForceMotionSpaces(self, force_space_dimension, axis=(0, 0, 1)):
+        if not 0 <= force_space_dimension <= 3:
+            raise ValueError("Force space dimension should be between 0 and 3 in MotionForceTask::parametrizeForceMotionSpaces\n")
+        a = np.asarray(axis, dtype=float)
+        if force_space_dimension in (1, 2):
+            if np.linalg.norm(a) < 1e-2:
+                raise ValueError("Force or motion axis should be a non singular vector in MotionForceTask::parametrizeForceMotionSpaces\n")
+            a = a / np.linalg.norm(a)
+            for i in range(3):
+                self._cfg.force_axis[i] = a[i]
+        self._cfg.force_space_dimension = int(force_space_dimension)
+        self._sync_cfg()
+
+    def parametrizeMomentRotMotionSpaces(self, moment_space_dimension, axis=(0, 0, 1)):
+        if not 0 <= moment_space_dimension <= 3:
+            raise ValueError("Moment space dimension should be between 0 and 3 in MotionForceTask::parametrizeMomentRotMotionSpaces\n")
+        a = np.asarray(axis, dtype=float)
+        if moment_space_dimension in (1, 2):
+            if np.linalg.norm(a) < 1e-2:
+                raise ValueError("Moment or rot motion axis should be a non singular vector in MotionForceTask::parametrizeMomentRotMotionSpaces\n")
+            a = a / np.linalg.norm(a)
+            for i in range(3):
+                self._cfg.moment_axis[i] = a[i]
+        self._cfg.moment_space_dimension = int(moment_space_dimension)
+        self._sync_cfg()
+
+    def setClosedLoopForceControl(self, on=True):
+        self._cfg.closed_loop_force = int(on)
+        self._sync_cfg()
+
+    def setClosedLoopMomentControl(self, on=True):
+        self._cfg.closed_loop_moment = int(on)
+        self._sync_cfg()
+
+    def enableVelocitySaturation(self, linear_vel_sat=0.3, angular_vel_sat=np.pi / 3):
+        if linear_vel_sat <= 0 or angular_vel_sat <= 0:
+            raise ValueError("Velocity saturation values should be strictly positive or zero in MotionForceTask::enableVelocitySaturation\n")
+        self._cfg.use_velocity_saturation = 1
+        self._cfg.linear_saturation_velocity, self._cfg.angular_saturation_velocity = linear_vel_sat, angular_vel_sat
+        self._sync_cfg()
+
+    def disableVelocitySaturation(self):
+        self._cfg.use_velocity_saturation = 0
+        self._sync_cfg()
+
+    def disableInternalOtg(self):
+        """the internal OTG is not part of this path: desired state = goal state"""
+
+    def setSingularityHandlingBounds(self, s_min, s_max):
+        self._cfg.s_min, self._cfg.s_max = float(s_min), float(s_max)
+        self._sync_cfg()
+
+    def getSigmaValues(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_singularity(idx)[0]
+
+    def _flush(self):
+        if self._owner and self._pending:
+            rc, idx = self._owner
+            p = self._pending
+            if any(k in p for k in ("pos", "rot", "v", "w", "a", "alpha")):
+                rc._ctrl.set_mft_goals(idx, p.get("pos"), p.get("rot"), p.get("v"), p.get("w"), p.get("a"), p.get("alpha"))
+            if "f" in p or "m" in p:
+                rc._ctrl.set_mft_goal_wrench(idx, p.get("f"), p.get("m"))
+            if "sf" in p or "sm" in p:
+                rc._ctrl.set_mft_sensed_wrench(idx, p.get("sf"), p.get("sm"))
+            self._pending = {}
+
+
+class RobotController:
+    """reference src/RobotController.h:25-40: same ctor checks, same entry points, batched."""
+
+    def __init__(self, robot, tasks, introspection=False):
+        if len(tasks) == 0:
+            raise ValueError("RobotController must have at least one task")
+        for t in tasks:
+            if t.getConstRobotModel() is not robot:
+                raise ValueError("All tasks must have the same robot model in RobotController")
+        self._robot = robot
+        self._tasks = list(tasks)
+        self._ctrl = Controller(robot.model, [t._cfg for t in tasks], robot.batch, robot.device, introspection)
+        robot._controller = self
+        self._ctrl.set_state(robot.q(), robot.dq())
+        self._ctrl.reinitialize()  # tasks are constructed at the model's current state
+        for i, t in enumerate(self._tasks):
+            t._owner = (self, i)
+            t._flush()
+
+    def updateControllerTaskModels(self):
+        self._ctrl.update_task_models()
+
+    def computeControlTorques(self, out=None):
+        return self._ctrl.compute_control_torques(True, out)
+
+    def tick(self, out=None):
+        """fused updateControllerTaskModels() + computeControlTorques(): one kernel launch"""
+        return self._ctrl.tick(out)
+
+    def enableGravityCompensation(self, enable=True):
+        self._ctrl.enable_gravity_compensation(enable)
+
+    def reinitializeTasks(self):
+        self._ctrl.reinitialize()
+
+    def getTaskNames(self):
+        return [t.getTaskName() for t in self._tasks]
+
+    def _by_name(self, name, kind, label):
+        for t in self._tasks:
+            if t.getTaskName() == name:
+                if t.getTaskType() != kind:
+                    raise ValueError(f"Task {name} is not a {label}, and cannot be casted as such in RobotController::GetTaskByName")
+                return t
+        raise ValueError(f"Task {name} not found in RobotController::GetTaskByName")
+
+    def getJointTaskByName(self, name):
+        return self._by_name(name, _abi.JOINT_TASK, "JointTask")
+
+    def getMotionForceTaskByName(self, name):
+        return self._by_name(name, MOTION_FORCE_TASK, "MotionForceTask")

@@ -1,0 +1,801 @@
+// sai2b_host.cpp — host side of the C ABI in include/sai2b.h: configuration helpers (no GPU
+// needed), context/buffer management and kernel launches. The numerical work is in
+// sai2b_kernels.hip; there is no CPU compute path here — without a GPU sai2b_create() fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sai2b_launch.h"
+
+using sai2b::DevModel;
+using sai2b::DevParams;
+using sai2b::DevTask;
+constexpr int N = SAI2B_DOF;
+
+static thread_local std::string g_error;
+
+struct sai2b_ctx {
+	int B = 0, T = 0, device = 0;
+	bool introspection = false;
+	bool models_fresh = false;	// update_task_models() ran for the current state
+	bool params_dirty = true;
+	sai2b_robot_model model;
+	sai2b_task_config cfg[SAI2B_MAX_TASKS];
+	DevParams h_params;
+	DevParams* d_params = nullptr;
+	hipStream_t stream = nullptr;
+	double *q = nullptr, *dq = nullptr, *tau = nullptr;
+	std::vector<void*> allocs;
+	long long launches = 0, ticks = 0;
+	std::string error;
+};
+
+static int set_error(sai2b_ctx* ctx, int code, const std::string& msg) {
+	g_error = msg;
+	if (ctx) ctx->error = msg;
+	return code;
+}
+#define HIP_TRY(ctx, expr)                                                                         \
+	do {                                                                                           \
+		hipError_t e_ = (expr);                                                                    \
+		if (e_ != hipSuccess)                                                                      \
+			return set_error(ctx, SAI2B_RUNTIME_ERROR, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+	} while (0)
+
+// ------------------------------------------------------------------------------------------------
+// small host-side linear algebra for the configuration helpers
+// ------------------------------------------------------------------------------------------------
+static void rot_from_rpy(const double* rpy, double* R) {
+	const double cr = std::cos(rpy[0]), sr = std::sin(rpy[0]);
+	const double cp = std::cos(rpy[1]), sp = std::sin(rpy[1]);
+	const double cy = std::cos(rpy[2]), sy = std::sin(rpy[2]);
+	const double Rm[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr, sy * cp, sy * sp * sr + cy * cr,
+						  sy * sp * cr - cy * sr, -sp,		cp * sr,				 cp * cr};
+	std::memcpy(R, Rm, sizeof(Rm));
+}
+static void sym3_from6(const double* v, double* I) {
+	I[0] = v[0], I[4] = v[1], I[8] = v[2];
+	I[1] = I[3] = v[3];
+	I[2] = I[6] = v[4];
+	I[5] = I[7] = v[5];
+}
+// cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 7): A = V diag(w) V^T
+static void sym_eig(int n, const double* A_in, double* w, double* V) {
+	double A[49];
+	std::memcpy(A, A_in, sizeof(double) * n * n);
+	for (int i = 0; i < n * n; i++) V[i] = 0;
+	for (int i = 0; i < n; i++) V[i * n + i] = 1;
+	for (int sweep = 0; sweep < 64; sweep++) {
+		double off = 0;
+		for (int i = 0; i < n; i++)
+			for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
+		if (off < 1e-300) break;
+		for (int p = 0; p < n; p++)
+			for (int q = p + 1; q < n; q++) {
+				const double apq = A[p * n + q];
+				if (std::fabs(apq) < 1e-300) continue;
+				const double theta = (A[q * n + q] - A[p * n + p]) / (2 * apq);
+				const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
+				const double c = 1 / std::sqrt(t * t + 1), s = t * c;
+				for (int k = 0; k < n; k++) {
+					const double akp = A[k * n + p], akq = A[k * n + q];
+					A[k * n + p] = c * akp - s * akq;
+					A[k * n + q] = s * akp + c * akq;
+				}
+				for (int k = 0; k < n; k++) {
+					const double apk = A[p * n + k], aqk = A[q * n + k];
+					A[p * n + k] = c * apk - s * aqk;
+					A[q * n + k] = s * apk + c * aqk;
+				}
+				for (int k = 0; k < n; k++) {
+					const double vkp = V[k * n + p], vkq = V[k * n + q];
+					V[k * n + p] = c * vkp - s * vkq;
+					V[k * n + q] = s * vkp + c * vkq;
+				}
+			}
+	}
+	for (int i = 0; i < n; i++) w[i] = A[i * n + i];
+}
+// Orthogonal projector onto the range of the 3 x nd matrix whose columns are the given directions,
+// with the rank rule of Sai2Model::matrixRangeBasis (sigma_i / sigma_0 >= 1e-3, zero if
+// sigma_0 < 1e-3). Returns the rank. (MotionForceTask.cpp:55-87,146-152)
+static int direction_projector(int nd, const double* dirs, double* P) {
+	for (int i = 0; i < 9; i++) P[i] = 0;
+	if (nd <= 0) return 0;
+	double G[9] = {0};
+	for (int d = 0; d < nd; d++)
+		for (int i = 0; i < 3; i++)
+			for (int j = 0; j < 3; j++) G[3 * i + j] += dirs[3 * d + i] * dirs[3 * d + j];
+	double w[3], V[9];
+	sym_eig(3, G, w, V);
+	double s[3], s0 = 0;
+	for (int i = 0; i < 3; i++) {
+		s[i] = std::sqrt(std::max(w[i], 0.0));
+		s0 = std::max(s0, s[i]);
+	}
+	if (s0 < 1e-3) return 0;
+	int rank = 0;
+	const int p = std::min(3, nd);
+	// keep at most min(3, nd) directions, those above the relative tolerance
+	int order[3] = {0, 1, 2};
+	std::sort(order, order + 3, [&](int a, int b) { return s[a] > s[b]; });
+	for (int k = 0; k < p; k++)
+		if (k == 0 || s[order[k]] / s0 >= 1e-3) rank++;
+	if (rank == 3) {
+		P[0] = P[4] = P[8] = 1;
+		return 3;
+	}
+	for (int k = 0; k < rank; k++) {
+		const int c = order[k];
+		for (int i = 0; i < 3; i++)
+			for (int j = 0; j < 3; j++) P[3 * i + j] += V[3 * i + c] * V[3 * j + c];
+	}
+	return rank;
+}
+// rank of a k x 7 matrix by Gaussian elimination with full pivoting (Eigen::FullPivLU::rank(),
+// JointTask.cpp:34-35)
+static int full_pivot_rank(int rows, int cols, const double* A_in) {
+	std::vector<double> A(A_in, A_in + rows * cols);
+	int rank = 0;
+	double maxpiv = 0;
+	const int p = std::min(rows, cols);
+	std::vector<int> rused(rows, 0), cused(cols, 0);
+	for (int step = 0; step < p; step++) {
+		int pr = -1, pc = -1;
+		double best = 0;
+		for (int r = 0; r < rows; r++)
+			if (!rused[r])
+				for (int c = 0; c < cols; c++)
+					if (!cused[c] && std::fabs(A[r * cols + c]) > best) {
+						best = std::fabs(A[r * cols + c]);
+						pr = r;
+						pc = c;
+					}
+		if (pr < 0) break;
+		if (step == 0) maxpiv = best;
+		if (best <= maxpiv * 2.220446049250313e-16 * p) break;
+		rank++;
+		rused[pr] = cused[pc] = 1;
+		for (int r = 0; r < rows; r++) {
+			if (rused[r]) continue;
+			const double f = A[r * cols + pc] / A[pr * cols + pc];
+			for (int c = 0; c < cols; c++) A[r * cols + c] -= f * A[pr * cols + c];
+		}
+	}
+	return rank;
+}
+
+// ------------------------------------------------------------------------------------------------
+// configuration helpers (host only)
+// ------------------------------------------------------------------------------------------------
+extern "C" int sai2b_model_merge_fixed_body(sai2b_robot_model* md, int link, const double xyz[3], const double rpy[3],
+											double mass, const double com[3], const double inertia[6]) {
+	if (!md || link < 0 || link >= N || !xyz || !rpy || !com || !inertia)
+		return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "sai2b_model_merge_fixed_body: bad arguments");
+	double Rf[9], Ic[9], Iw[9] = {0};
+	rot_from_rpy(rpy, Rf);
+	sym3_from6(inertia, Ic);
+	for (int i = 0; i < 3; i++)
+		for (int j = 0; j < 3; j++)
+			for (int a = 0; a < 3; a++)
+				for (int b = 0; b < 3; b++) Iw[3 * i + j] += Rf[3 * i + a] * Ic[3 * a + b] * Rf[3 * j + b];
+	double c_child[3];
+	for (int i = 0; i < 3; i++) c_child[i] = xyz[i] + Rf[3 * i] * com[0] + Rf[3 * i + 1] * com[1] + Rf[3 * i + 2] * com[2];
+	const double m_parent = md->link_mass[link], m_total = m_parent + mass;
+	double c_parent[3], c_new[3], I_parent[9], I_new[9];
+	for (int i = 0; i < 3; i++) {
+		c_parent[i] = md->link_com[link][i];
+		c_new[i] = (m_parent * c_parent[i] + mass * c_child[i]) / m_total;
+	}
+	sym3_from6(md->link_inertia[link], I_parent);
+	auto shifted = [&](const double* I, double m, const double* c, double* out) {
+		const double d[3] = {c[0] - c_new[0], c[1] - c_new[1], c[2] - c_new[2]};
+		const double d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+		for (int i = 0; i < 3; i++)
+			for (int j = 0; j < 3; j++) out[3 * i + j] += I[3 * i + j] + m * ((i == j ? d2 : 0.0) - d[i] * d[j]);
+	};
+	for (int i = 0; i < 9; i++) I_new[i] = 0;
+	shifted(I_parent, m_parent, c_parent, I_new);
+	shifted(Iw, mass, c_child, I_new);
+	md->link_mass[link] = m_total;
+	for (int i = 0; i < 3; i++) md->link_com[link][i] = c_new[i];
+	double* o = md->link_inertia[link];
+	o[0] = I_new[0], o[1] = I_new[4], o[2] = I_new[8], o[3] = I_new[1], o[4] = I_new[2], o[5] = I_new[5];
+	return SAI2B_OK;
+}
+
+extern "C" int sai2b_panda_model(sai2b_robot_model* md) {
+	if (!md) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "sai2b_panda_model: null");
+	std::memset(md, 0, sizeof(*md));
+	md->dof = N;
+	// examples/15-haptic_control_impedance_type/panda_arm.urdf:118-178 (joint origins / limits)
+	struct Jt {
+		double x, y, z, roll, lo, hi, effort;
+	};
+	const Jt joints[N] = {{0, 0, 0.333, 0, -2.8973, 2.8973, 87},
+						  {0, 0, 0, -1.57079632679, -1.7628, 1.7628, 87},
+						  {0, -0.316, 0, 1.57079632679, -2.8973, 2.8973, 87},
+						  {0.0825, 0, 0, 1.57079632679, -3.0718, -0.0698, 87},
+						  {-0.0825, 0.384, 0, -1.57079632679, -2.8973, 2.8973, 12},
+						  {0, 0, 0, 1.57079632679, -0.0175, 3.7525, 12},
+						  {0.088, 0, 0, 1.57079632679, -2.8973, 2.8973, 12}};
+	// panda_arm.urdf:17-104 (link inertials: mass, COM, diagonal inertia)
+	struct Lk {
+		double m, cx, cy, cz, ixx, iyy, izz;
+	};
+	const Lk links[N] = {{3, 0, 0, -0.07, 0.3, 0.3, 0.3},	 {3, 0, -0.1, 0, 0.3, 0.3, 0.3},
+						 {2, 0.04, 0, -0.05, 0.2, 0.2, 0.2}, {2, -0.04, 0.05, 0, 0.2, 0.2, 0.2},
+						 {2, 0, 0, -0.15, 0.2, 0.2, 0.2},	 {1.5, 0.06, 0, 0, 0.1, 0.1, 0.1},
+						 {1.8, 0, 0, 0.17, 0.09, 0.05, 0.07}};
+	for (int i = 0; i < N; i++) {
+		md->joint_xyz[i][0] = joints[i].x, md->joint_xyz[i][1] = joints[i].y, md->joint_xyz[i][2] = joints[i].z;
+		md->joint_rpy[i][0] = joints[i].roll;
+		md->q_lower[i] = joints[i].lo, md->q_upper[i] = joints[i].hi, md->effort[i] = joints[i].effort;
+		md->link_mass[i] = links[i].m;
+		md->link_com[i][0] = links[i].cx, md->link_com[i][1] = links[i].cy, md->link_com[i][2] = links[i].cz;
+		md->link_inertia[i][0] = links[i].ixx, md->link_inertia[i][1] = links[i].iyy, md->link_inertia[i][2] = links[i].izz;
+	}
+	md->gravity[2] = -9.81;
+	// fixed "end-effector" body (panda_arm.urdf:105-116) on joint_ee (:179-183)
+	const double xyz[3] = {0, 0, 0.15}, zero[3] = {0, 0, 0}, inertia[6] = {0.01, 0.01, 0.01, 0, 0, 0};
+	return sai2b_model_merge_fixed_body(md, 6, xyz, zero, 0.2, zero, inertia);
+}
+
+static void singularity_defaults(sai2b_task_config* c) {
+	c->s_min = 6e-3, c->s_max = 6e-2;  // MotionForceTask.cpp:197
+	c->s_abs_tol = 1e-3;			   // SingularityHandler.cpp:11-19
+	c->type_1_tol = 0.5;
+	c->type_2_torque_ratio = 1e-2;
+	c->type_2_angle_threshold = 5 * M_PI / 180;
+	c->perturb_step_size = 5;
+	c->sh_buffer_size = SAI2B_SH_HISTORY;
+	c->kp_type_1 = 50, c->kv_type_1 = 14, c->kv_type_2 = 5;
+	c->enforce_type_1_strategy = 0;	 // SingularityHandler.cpp:63-64
+	c->enforce_handling_strategy = 1;
+}
+
+extern "C" int sai2b_default_joint_task(sai2b_task_config* c, const char* name, int task_dof, const double* selection) {
+	if (!c) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "sai2b_default_joint_task: null config");
+	std::memset(c, 0, sizeof(*c));
+	c->type = SAI2B_JOINT_TASK;
+	std::snprintf(c->name, sizeof(c->name), "%s", name ? name : "joint_task");
+	c->loop_timestep = 0.001;
+	c->dynamic_decoupling_type = SAI2B_BOUNDED_INERTIA_ESTIMATES;
+	c->bie_threshold = 0.1;
+	if (!selection) {
+		c->task_dof = N;
+		for (int i = 0; i < N; i++) c->joint_selection[i * N + i] = 1;
+	} else {
+		if (task_dof < 1 || task_dof > N)
+			return set_error(nullptr, SAI2B_INVALID_ARGUMENT,
+							 "joint selection matrix size not consistent with robot dof in JointTask constructor\n");
+		if (full_pivot_rank(task_dof, N, selection) != task_dof)
+			return set_error(nullptr, SAI2B_INVALID_ARGUMENT,
+							 "joint selection matrix is not full rank in JointTask constructor\n");
+		c->task_dof = task_dof;
+		std::memcpy(c->joint_selection, selection, sizeof(double) * task_dof * N);
+	}
+	for (int i = 0; i < N; i++) {
+		c->kp[i] = 50.0, c->kv[i] = 14.0, c->ki[i] = 0.0;  // JointTask.h:32-34
+		c->saturation_velocity[i] = M_PI / 3.0;				 // JointTask.h:44
+	}
+	return SAI2B_OK;
+}
+
+extern "C" int sai2b_default_motion_force_task(sai2b_task_config* c, const char* name, int link,
+											   const double frame_pos[3], const double* frame_rot, int n_trans,
+											   const double* dirs_trans, int n_rot, const double* dirs_rot) {
+	if (!c) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "sai2b_default_motion_force_task: null config");
+	std::memset(c, 0, sizeof(*c));
+	c->type = SAI2B_MOTION_FORCE_TASK;
+	const bool partial = !(n_trans < 0 && n_rot < 0);
+	std::snprintf(c->name, sizeof(c->name), "%s", name ? name : (partial ? "partial_motion_force_task" : "motion_force_task"));
+	c->loop_timestep = 0.001;
+	if (link < 0 || link >= N) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "MotionForceTask: link index out of range");
+	c->link = link;
+	for (int i = 0; i < 3; i++) c->frame_pos[i] = frame_pos ? frame_pos[i] : 0.0;
+	for (int i = 0; i < 9; i++) c->frame_rot[i] = frame_rot ? frame_rot[i] : (i % 4 == 0 ? 1.0 : 0.0);
+	const char* empty_msg =
+		"controlled_directions_translation and controlled_directions_rotation cannot both be empty in "
+		"MotionForceTask::MotionForceTask\n";
+	if (!partial) {
+		for (int i = 0; i < 6; i++) c->partial_projection[i * 6 + i] = 1;
+		c->pos_range = c->ori_range = 3;
+	} else {
+		if (std::max(n_trans, 0) + std::max(n_rot, 0) == 0) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, empty_msg);
+		if ((n_trans > 0 && !dirs_trans) || (n_rot > 0 && !dirs_rot))
+			return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "MotionForceTask: null direction array");
+		double Pp[9], Po[9];
+		c->pos_range = direction_projector(n_trans, dirs_trans, Pp);
+		c->ori_range = direction_projector(n_rot, dirs_rot, Po);
+		for (int i = 0; i < 3; i++)
+			for (int j = 0; j < 3; j++) {
+				c->partial_projection[i * 6 + j] = Pp[3 * i + j];
+				c->partial_projection[(3 + i) * 6 + 3 + j] = Po[3 * i + j];
+			}
+		if (c->pos_range + c->ori_range == 0) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, empty_msg);
+	}
+	c->dynamic_decoupling_type = SAI2B_BOUNDED_INERTIA_ESTIMATES;
+	c->bie_threshold = 0.1;
+	for (int i = 0; i < 3; i++) {  // MotionForceTask.h:44-55
+		c->kp_pos[i] = 100.0, c->kv_pos[i] = 20.0, c->ki_pos[i] = 0.0;
+		c->kp_ori[i] = 200.0, c->kv_ori[i] = 28.3, c->ki_ori[i] = 0.0;
+		c->kp_force[i] = 0.7, c->kv_force[i] = 10.0, c->ki_force[i] = 1.3;
+		c->kp_moment[i] = 0.7, c->kv_moment[i] = 10.0, c->ki_moment[i] = 1.3;
+	}
+	c->kff_force = c->kff_moment = 0.95;
+	c->max_force_feedback = 20.0, c->max_moment_feedback = 10.0;
+	c->force_axis[2] = c->moment_axis[2] = 1.0;
+	c->linear_saturation_velocity = 0.3, c->angular_saturation_velocity = M_PI / 3;
+	c->sensor_rot[0] = c->sensor_rot[4] = c->sensor_rot[8] = 1.0;
+	singularity_defaults(c);
+	return SAI2B_OK;
+}
+
+extern "C" int sai2b_validate_tasks(const sai2b_task_config* tasks, int n_tasks, char* msg, int msg_len) {
+	std::string err;
+	if (!tasks || n_tasks <= 0)
+		err = "RobotController must have at least one task";
+	else if (n_tasks > SAI2B_MAX_TASKS)
+		err = "too many tasks for this build (SAI2B_MAX_TASKS)";
+	bool closed = false;
+	for (int i = 0; err.empty() && i < n_tasks; i++) {
+		const sai2b_task_config& t = tasks[i];
+		if (t.type != SAI2B_JOINT_TASK && t.type != SAI2B_MOTION_FORCE_TASK)
+			err = "task type must be JOINT_TASK or MOTION_FORCE_TASK";
+		else if (t.loop_timestep != tasks[0].loop_timestep)
+			err = "All tasks must have the same loop timestep in RobotController";
+		for (int j = 0; err.empty() && j < i; j++)
+			if (std::strncmp(t.name, tasks[j].name, sizeof(t.name)) == 0) err = "Tasks in RobotController must have unique names";
+		if (err.empty() && closed)
+			err = std::string("task [") + t.name +
+				  "] cannot be added to the controller because it is in the nullspace of a full joint task";
+		if (err.empty() && t.type == SAI2B_JOINT_TASK) {
+			if (t.task_dof < 1 || t.task_dof > N)
+				err = "joint selection matrix size not consistent with robot dof in JointTask constructor\n";
+			else if (full_pivot_rank(t.task_dof, N, t.joint_selection) != t.task_dof)
+				err = "joint selection matrix is not full rank in JointTask constructor\n";
+			else if (t.task_dof == N)
+				closed = true;	// isFullJointTask (RobotController.cpp:44-49)
+			for (int k = 0; err.empty() && k < t.task_dof; k++)
+				if (t.kp[k] < 0 || t.kv[k] < 0 || t.ki[k] < 0) err = "gains must be positive or zero in JointTask::setGains\n";
+		}
+		if (err.empty() && t.type == SAI2B_MOTION_FORCE_TASK) {
+			if (t.link < 0 || t.link >= N) err = "MotionForceTask: link index out of range";
+			if (t.force_space_dimension < 0 || t.force_space_dimension > 3)
+				err = "Force space dimension should be between 0 and 3 in MotionForceTask::parametrizeForceMotionSpaces\n";
+			if (t.moment_space_dimension < 0 || t.moment_space_dimension > 3)
+				err = "Moment space dimension should be between 0 and 3 in MotionForceTask::parametrizeMomentRotMotionSpaces\n";
+			if (t.sh_buffer_size < 1 || t.sh_buffer_size > SAI2B_SH_HISTORY) err = "singularity history size must be in [1, 200]";
+			for (int k = 0; err.empty() && k < 3; k++)
+				if (t.kp_pos[k] < 0 || t.kv_pos[k] < 0 || t.ki_pos[k] < 0 || t.kp_ori[k] < 0 || t.kv_ori[k] < 0 || t.ki_ori[k] < 0)
+					err = "all gains should be positive or zero in MotionForceTask::setPosControlGains\n";
+		}
+		if (err.empty() && t.use_velocity_saturation) {
+			if (t.type == SAI2B_MOTION_FORCE_TASK && (t.linear_saturation_velocity <= 0 || t.angular_saturation_velocity <= 0))
+				err = "Velocity saturation values should be strictly positive or zero in MotionForceTask::enableVelocitySaturation\n";
+			if (t.type == SAI2B_JOINT_TASK)
+				for (int k = 0; k < t.task_dof; k++)
+					if (t.saturation_velocity[k] <= 0) err = "saturation velocity must be positive in JointTask::enableVelocitySaturation\n";
+		}
+	}
+	// implementation restriction: one shared bounded-inertia estimate per tick
+	double thr = -1;
+	for (int i = 0; err.empty() && i < n_tasks; i++)
+		if (tasks[i].dynamic_decoupling_type == SAI2B_BOUNDED_INERTIA_ESTIMATES) {
+			if (thr >= 0 && tasks[i].bie_threshold != thr)
+				err = "tasks using BOUNDED_INERTIA_ESTIMATES must share one threshold in this build";
+			thr = tasks[i].bie_threshold;
+		}
+	if (msg && msg_len > 0) std::snprintf(msg, msg_len, "%s", err.c_str());
+	if (!err.empty()) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, err);
+	return SAI2B_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+static void fill_dev_task(const sai2b_task_config& c, DevTask& d) {
+	d.type = c.type;
+	d.decoupling = c.dynamic_decoupling_type;
+	d.bie_threshold = c.bie_threshold;
+	d.dt = c.loop_timestep;
+	d.k0 = c.type == SAI2B_JOINT_TASK ? c.task_dof : 0;
+	for (int i = 0; i < N * N; i++) d.S[i] = 0;
+	bool ident = (d.k0 == N);
+	for (int i = 0; i < d.k0; i++)
+		for (int j = 0; j < N; j++) {
+			d.S[i * N + j] = c.joint_selection[i * N + j];
+			if (d.S[i * N + j] != (i == j ? 1.0 : 0.0)) ident = false;
+		}
+	d.full_selection = ident ? 1 : 0;
+	for (int i = 0; i < N; i++) d.kp[i] = c.kp[i], d.kv[i] = c.kv[i], d.ki[i] = c.ki[i], d.vsat[i] = c.saturation_velocity[i];
+	d.use_vsat = c.use_velocity_saturation;
+	d.link = c.link;
+	std::memcpy(d.frame_pos, c.frame_pos, sizeof(d.frame_pos));
+	std::memcpy(d.frame_rot, c.frame_rot, sizeof(d.frame_rot));
+	std::memcpy(d.P, c.partial_projection, sizeof(d.P));
+	bool pid = true;
+	for (int i = 0; i < 36; i++)
+		if (c.partial_projection[i] != ((i % 7 == 0) ? 1.0 : 0.0)) pid = false;
+	d.full_projection = pid ? 1 : 0;
+	d.rank = c.pos_range + c.ori_range;
+	d.in_frame = c.parametrization_in_compliant_frame;
+	for (int i = 0; i < 3; i++) {
+		d.kp_pos[i] = c.kp_pos[i], d.kv_pos[i] = c.kv_pos[i], d.ki_pos[i] = c.ki_pos[i];
+		d.kp_ori[i] = c.kp_ori[i], d.kv_ori[i] = c.kv_ori[i], d.ki_ori[i] = c.ki_ori[i];
+		d.kp_f[i] = c.kp_force[i], d.kv_f[i] = c.kv_force[i], d.ki_f[i] = c.ki_force[i];
+		d.kp_m[i] = c.kp_moment[i], d.kv_m[i] = c.kv_moment[i], d.ki_m[i] = c.ki_moment[i];
+		d.faxis[i] = c.force_axis[i], d.maxis[i] = c.moment_axis[i];
+		d.sensor_pos[i] = c.sensor_pos[i];
+	}
+	std::memcpy(d.sensor_rot, c.sensor_rot, sizeof(d.sensor_rot));
+	d.kff_f = c.kff_force, d.kff_m = c.kff_moment, d.max_f = c.max_force_feedback, d.max_m = c.max_moment_feedback;
+	d.cl_force = c.closed_loop_force, d.cl_moment = c.closed_loop_moment;
+	d.fdim = c.force_space_dimension, d.mdim = c.moment_space_dimension;
+	d.lin_vsat = c.linear_saturation_velocity, d.ang_vsat = c.angular_saturation_velocity;
+	d.s_min = c.s_min, d.s_max = c.s_max, d.s_abs_tol = c.s_abs_tol, d.type_1_tol = c.type_1_tol;
+	d.t2_ratio = c.type_2_torque_ratio, d.t2_angle = c.type_2_angle_threshold, d.perturb = c.perturb_step_size;
+	d.sh_cap = c.sh_buffer_size;
+	d.kp1 = c.kp_type_1, d.kv1 = c.kv_type_1, d.kv2 = c.kv_type_2;
+	d.enforce_t1 = c.enforce_type_1_strategy, d.enforce = c.enforce_handling_strategy;
+}
+
+template <class T>
+static int dev_alloc(sai2b_ctx* ctx, T** p, size_t count) {
+	void* v = nullptr;
+	HIP_TRY(ctx, hipMalloc(&v, std::max<size_t>(count, 1) * sizeof(T)));
+	HIP_TRY(ctx, hipMemsetAsync(v, 0, std::max<size_t>(count, 1) * sizeof(T), ctx->stream));
+	ctx->allocs.push_back(v);
+	*p = (T*)v;
+	return SAI2B_OK;
+}
+
+static int upload_params(sai2b_ctx* ctx) {
+	if (!ctx->params_dirty) return SAI2B_OK;
+	// stream-ordered so that kernels already enqueued keep the parameters they were launched with
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_params, &ctx->h_params, sizeof(DevParams), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // h_params may be edited again right after
+	ctx->params_dirty = false;
+	return SAI2B_OK;
+}
+
+static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai2b_task_config* tasks, int n_tasks,
+					   int batch, int device) {
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+		return set_error(ctx, SAI2B_RUNTIME_ERROR, "sai2b_create: no HIP device available (this library has no CPU path)");
+	if (device < 0 || device >= ndev) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_create: bad device index");
+	HIP_TRY(ctx, hipSetDevice(device));
+	HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+	ctx->B = batch, ctx->T = n_tasks, ctx->device = device;
+	ctx->model = *model;
+	DevParams& hp = ctx->h_params;
+	std::memset(&hp, 0, sizeof(hp));
+	hp.B = batch, hp.n_tasks = n_tasks;
+	for (int i = 0; i < N; i++) {
+		rot_from_rpy(model->joint_rpy[i], hp.model.E[i]);
+		for (int k = 0; k < 3; k++) hp.model.xyz[i][k] = model->joint_xyz[i][k], hp.model.com[i][k] = model->link_com[i][k];
+		for (int k = 0; k < 6; k++) hp.model.inertia[i][k] = model->link_inertia[i][k];
+		hp.model.mass[i] = model->link_mass[i];
+		hp.model.q_lower[i] = model->q_lower[i], hp.model.q_upper[i] = model->q_upper[i], hp.model.effort[i] = model->effort[i];
+	}
+	for (int k = 0; k < 3; k++) hp.model.gravity[k] = model->gravity[k];
+	const size_t Bs = (size_t)batch;
+	int rc;
+	if ((rc = dev_alloc(ctx, &ctx->d_params, 1))) return rc;
+	if ((rc = dev_alloc(ctx, &ctx->q, N * Bs))) return rc;
+	if ((rc = dev_alloc(ctx, &ctx->dq, N * Bs))) return rc;
+	if ((rc = dev_alloc(ctx, &ctx->tau, N * Bs))) return rc;
+	hp.q = ctx->q, hp.dq = ctx->dq, hp.tau = ctx->tau;
+	for (int t = 0; t < n_tasks; t++) {
+		ctx->cfg[t] = tasks[t];
+		DevTask& d = hp.task[t];
+		fill_dev_task(tasks[t], d);
+		if (tasks[t].type == SAI2B_MOTION_FORCE_TASK) {
+			if ((rc = dev_alloc(ctx, &d.goals, sai2b::MFT_GOAL_ROWS * Bs))) return rc;
+			if ((rc = dev_alloc(ctx, &d.sensed, 6 * Bs))) return rc;
+			if ((rc = dev_alloc(ctx, &d.state, sai2b::MFT_STATE_ROWS * Bs))) return rc;
+			if ((rc = dev_alloc(ctx, &d.istate, sai2b::MFT_ISTATE_ROWS * Bs))) return rc;
+		} else {
+			if ((rc = dev_alloc(ctx, &d.goals, 3 * (size_t)d.k0 * Bs))) return rc;
+			if ((rc = dev_alloc(ctx, &d.state, (size_t)d.k0 * Bs))) return rc;
+		}
+	}
+	ctx->params_dirty = true;
+	if ((rc = upload_params(ctx))) return rc;
+	// the reference constructs tasks from the model's current state (q = 0 until set_state)
+	if (sai2b_launch_reinit(ctx->d_params, ctx->B, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "reinit launch failed");
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return SAI2B_OK;
+}
+
+extern "C" sai2b_ctx* sai2b_create(const sai2b_robot_model* model, const sai2b_task_config* tasks, int n_tasks, int batch,
+								   int device) {
+	if (!model || model->dof != N) {
+		set_error(nullptr, SAI2B_INVALID_ARGUMENT, "sai2b_create: model must have dof == 7 in this build");
+		return nullptr;
+	}
+	if (batch < 1) {
+		set_error(nullptr, SAI2B_INVALID_ARGUMENT, "sai2b_create: batch must be >= 1");
+		return nullptr;
+	}
+	char msg[256];
+	if (sai2b_validate_tasks(tasks, n_tasks, msg, sizeof(msg))) return nullptr;
+	sai2b_ctx* ctx = new sai2b_ctx();
+	if (create_impl(ctx, model, tasks, n_tasks, batch, device) != SAI2B_OK) {
+		std::string keep = ctx->error;
+		sai2b_destroy(ctx);
+		g_error = keep;
+		return nullptr;
+	}
+	return ctx;
+}
+
+extern "C" void sai2b_destroy(sai2b_ctx* ctx) {
+	if (!ctx) return;
+	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	for (void* p : ctx->allocs) (void)hipFree(p);
+	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+extern "C" const char* sai2b_last_error(const sai2b_ctx* ctx) { return ctx ? ctx->error.c_str() : g_error.c_str(); }
+extern "C" int sai2b_batch(const sai2b_ctx* ctx) { return ctx ? ctx->B : 0; }
+extern "C" int sai2b_num_tasks(const sai2b_ctx* ctx) { return ctx ? ctx->T : 0; }
+
+extern "C" int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_task_config* cfg) {
+	if (!ctx || !cfg || task < 0 || task >= ctx->T) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_update_task_config: bad arguments");
+	const sai2b_task_config& old = ctx->cfg[task];
+	if (cfg->type != old.type || cfg->task_dof != old.task_dof || cfg->link != old.link ||
+		std::memcmp(cfg->joint_selection, old.joint_selection, sizeof(old.joint_selection)) != 0 ||
+		std::memcmp(cfg->partial_projection, old.partial_projection, sizeof(old.partial_projection)) != 0)
+		return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_update_task_config: structural fields must not change");
+	sai2b_task_config all[SAI2B_MAX_TASKS];
+	for (int t = 0; t < ctx->T; t++) all[t] = ctx->cfg[t];
+	all[task] = *cfg;
+	char msg[256];
+	if (sai2b_validate_tasks(all, ctx->T, msg, sizeof(msg))) return set_error(ctx, SAI2B_INVALID_ARGUMENT, msg);
+	ctx->cfg[task] = *cfg;
+	DevTask& d = ctx->h_params.task[task];
+	DevTask keep = d;
+	fill_dev_task(*cfg, d);
+	d.goals = keep.goals, d.sensed = keep.sensed, d.state = keep.state, d.istate = keep.istate;
+	d.dbg_tau = keep.dbg_tau, d.dbg_N = keep.dbg_N, d.dbg_sigma = keep.dbg_sigma, d.dbg_J = keep.dbg_J, d.dbg_pose = keep.dbg_pose;
+	ctx->params_dirty = true;
+	return SAI2B_OK;
+}
+
+extern "C" int sai2b_enable_gravity_compensation(sai2b_ctx* ctx, int enable) {
+	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	ctx->h_params.gravity_comp = enable ? 1 : 0;
+	ctx->params_dirty = true;
+	return SAI2B_OK;
+}
+
+static int copy_rows(sai2b_ctx* ctx, double* dst, const double* src, size_t rows, int on_device) {
+	if (!src) return SAI2B_OK;
+	HIP_TRY(ctx, hipMemcpyAsync(dst, src, rows * (size_t)ctx->B * sizeof(double),
+								on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+	if (!on_device) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // pageable host memory may be reused by the caller
+	return SAI2B_OK;
+}
+
+extern "C" int sai2b_set_state(sai2b_ctx* ctx, const double* q, const double* dq, int on_device) {
+	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	int rc;
+	if ((rc = copy_rows(ctx, ctx->q, q, N, on_device))) return rc;
+	if ((rc = copy_rows(ctx, ctx->dq, dq, N, on_device))) return rc;
+	ctx->models_fresh = false;
+	return SAI2B_OK;
+}
+
+static int mft_task_check(sai2b_ctx* ctx, int task, const char* fn) {
+	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	if (task < 0 || task >= ctx->T || ctx->cfg[task].type != SAI2B_MOTION_FORCE_TASK)
+		return set_error(ctx, SAI2B_INVALID_ARGUMENT, std::string(fn) + ": task is not a MotionForceTask");
+	return hipSetDevice(ctx->device) == hipSuccess ? SAI2B_OK : set_error(ctx, SAI2B_RUNTIME_ERROR, "hipSetDevice failed");
+}
+
+extern "C" int sai2b_set_mft_goals(sai2b_ctx* ctx, int task, const double* pos, const double* rot, const double* lin_vel,
+								   const double* ang_vel, const double* lin_acc, const double* ang_acc, int on_device) {
+	int rc = mft_task_check(ctx, task, "sai2b_set_mft_goals");
+	if (rc) return rc;
+	double* G = ctx->h_params.task[task].goals;
+	const size_t B = ctx->B;
+	if ((rc = copy_rows(ctx, G, pos, 3, on_device))) return rc;
+	if ((rc = copy_rows(ctx, G + 3 * B, rot, 9, on_device))) return rc;
+	if ((rc = copy_rows(ctx, G + 12 * B, lin_vel, 3, on_device))) return rc;
+	if ((rc = copy_rows(ctx, G + 15 * B, ang_vel, 3, on_device))) return rc;
+	if ((rc = copy_rows(ctx, G + 18 * B, lin_acc, 3, on_device))) return rc;
+	return copy_rows(ctx, G + 21 * B, ang_acc, 3, on_device);
+}
+
+extern "C" int sai2b_set_mft_goal_wrench(sai2b_ctx* ctx, int task, const double* force, const double* moment, int on_device) {
+	int rc = mft_task_check(ctx, task, "sai2b_set_mft_goal_wrench");
+	if (rc) return rc;
+	double* G = ctx->h_params.task[task].goals;
+	const size_t B = ctx->B;
+	if ((rc = copy_rows(ctx, G + 24 * B, force, 3, on_device))) return rc;
+	return copy_rows(ctx, G + 27 * B, moment, 3, on_device);
+}
+
+extern "C" int sai2b_set_mft_sensed_wrench(sai2b_ctx* ctx, int task, const double* force, const double* moment, int on_device) {
+	int rc = mft_task_check(ctx, task, "sai2b_set_mft_sensed_wrench");
+	if (rc) return rc;
+	double* S = ctx->h_params.task[task].sensed;
+	if ((rc = copy_rows(ctx, S, force, 3, on_device))) return rc;
+	return copy_rows(ctx, S + 3 * (size_t)ctx->B, moment, 3, on_device);
+}
+
+extern "C" int sai2b_set_jt_goals(sai2b_ctx* ctx, int task, const double* q_goal, const double* dq_goal, const double* ddq_goal,
+								  int on_device) {
+	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	if (task < 0 || task >= ctx->T || ctx->cfg[task].type != SAI2B_JOINT_TASK)
+		return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_set_jt_goals: task is not a JointTask");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	double* G = ctx->h_params.task[task].goals;
+	const size_t B = ctx->B, k0 = ctx->cfg[task].task_dof;
+	int rc;
+	if ((rc = copy_rows(ctx, G, q_goal, k0, on_device))) return rc;
+	if ((rc = copy_rows(ctx, G + k0 * B, dq_goal, k0, on_device))) return rc;
+	return copy_rows(ctx, G + 2 * k0 * B, ddq_goal, k0, on_device);
+}
+
+extern "C" int sai2b_reinitialize(sai2b_ctx* ctx) {
+	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	int rc = upload_params(ctx);
+	if (rc) return rc;
+	if (sai2b_launch_reinit(ctx->d_params, ctx->B, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "reinit launch failed");
+	ctx->launches++;
+	ctx->models_fresh = false;
+	return SAI2B_OK;
+}
+
+static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torque) {
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	int rc = upload_params(ctx);
+	if (rc) return rc;
+	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, commit_sh, with_comp, do_torque, ctx->stream))
+		return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
+	ctx->launches++;
+	return SAI2B_OK;
+}
+
+static int fetch_tau(sai2b_ctx* ctx, double* tau, int on_device) {
+	if (!tau) return SAI2B_OK;
+	HIP_TRY(ctx, hipMemcpyAsync(tau, ctx->tau, (size_t)N * ctx->B * sizeof(double),
+								on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+	if (!on_device) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return SAI2B_OK;
+}
+
+// The split API recomputes the (deterministic) task models inside compute_control_torques; what
+// update_task_models() adds is the once-per-tick singularity bookkeeping, which is why it is
+// committed there and not again by the torque pass that follows it (DESIGN.md "split API").
+extern "C" int sai2b_update_task_models(sai2b_ctx* ctx) {
+	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	int rc = launch_tick(ctx, /*commit_sh=*/1, /*with_comp=*/1, /*do_torque=*/0);
+	if (rc) return rc;
+	ctx->models_fresh = true;
+	return SAI2B_OK;
+}
+
+extern "C" int sai2b_compute_control_torques_ex(sai2b_ctx* ctx, double* tau, int on_device, int with_compensation) {
+	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	int rc = launch_tick(ctx, ctx->models_fresh ? 0 : 1, with_compensation, 1);
+	if (rc) return rc;
+	ctx->models_fresh = false;
+	ctx->ticks += ctx->B;
+	return fetch_tau(ctx, tau, on_device);
+}
+extern "C" int sai2b_compute_control_torques(sai2b_ctx* ctx, double* tau, int on_device) {
+	return sai2b_compute_control_torques_ex(ctx, tau, on_device, 1);
+}
+
+extern "C" int sai2b_tick(sai2b_ctx* ctx, double* tau, int on_device) {
+	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	int rc = launch_tick(ctx, 1, 1, 1);
+	if (rc) return rc;
+	ctx->models_fresh = false;
+	ctx->ticks += ctx->B;
+	return fetch_tau(ctx, tau, on_device);
+}
+
+extern "C" int sai2b_synchronize(sai2b_ctx* ctx) {
+	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return SAI2B_OK;
+}
+extern "C" void* sai2b_stream(sai2b_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" void* sai2b_device_buffer(sai2b_ctx* ctx, int which, int task) {
+	if (!ctx) return nullptr;
+	const bool task_ok = task >= 0 && task < ctx->T;
+	switch (which) {
+		case SAI2B_BUF_Q: return ctx->q;
+		case SAI2B_BUF_DQ: return ctx->dq;
+		case SAI2B_BUF_TAU: return ctx->tau;
+		case SAI2B_BUF_GOALS: return task_ok ? ctx->h_params.task[task].goals : nullptr;
+		case SAI2B_BUF_SENSED: return task_ok ? ctx->h_params.task[task].sensed : nullptr;
+		case SAI2B_BUF_STATE: return task_ok ? ctx->h_params.task[task].state : nullptr;
+	}
+	return nullptr;
+}
+
+extern "C" int sai2b_enable_introspection(sai2b_ctx* ctx, int enable) {
+	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (enable && !ctx->h_params.dbg_M) {
+		const size_t B = ctx->B;
+		int rc;
+		if ((rc = dev_alloc(ctx, &ctx->h_params.dbg_M, N * N * B))) return rc;
+		for (int t = 0; t < ctx->T; t++) {
+			DevTask& d = ctx->h_params.task[t];
+			if ((rc = dev_alloc(ctx, &d.dbg_tau, N * B))) return rc;
+			if ((rc = dev_alloc(ctx, &d.dbg_N, N * N * B))) return rc;
+			if (d.type == SAI2B_MOTION_FORCE_TASK) {
+				if ((rc = dev_alloc(ctx, &d.dbg_sigma, 8 * B))) return rc;
+				if ((rc = dev_alloc(ctx, &d.dbg_J, 6 * N * B))) return rc;
+				if ((rc = dev_alloc(ctx, &d.dbg_pose, 12 * B))) return rc;
+			}
+		}
+		ctx->params_dirty = true;
+	}
+	ctx->introspection = enable != 0;
+	return SAI2B_OK;
+}
+
+static int fetch_dbg(sai2b_ctx* ctx, double* dst, const double* src, size_t rows) {
+	if (!dst) return SAI2B_OK;
+	if (!ctx->introspection || !src)
+		return set_error(ctx, SAI2B_INVALID_ARGUMENT, "introspection is not enabled: call sai2b_enable_introspection() before the tick");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	HIP_TRY(ctx, hipMemcpy(dst, src, rows * (size_t)ctx->B * sizeof(double), hipMemcpyDeviceToHost));
+	return SAI2B_OK;
+}
+
+extern "C" int sai2b_get_task_nullspace(sai2b_ctx* ctx, int task, double* N_total) {
+	if (!ctx || task < 0 || task >= ctx->T) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "bad task index");
+	return fetch_dbg(ctx, N_total, ctx->h_params.task[task].dbg_N, N * N);
+}
+extern "C" int sai2b_get_task_torques(sai2b_ctx* ctx, int task, double* tau_task) {
+	if (!ctx || task < 0 || task >= ctx->T) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "bad task index");
+	return fetch_dbg(ctx, tau_task, ctx->h_params.task[task].dbg_tau, N);
+}
+extern "C" int sai2b_get_mft_singularity(sai2b_ctx* ctx, int task, double* sigma, double* alpha, double* ns_rank) {
+	int rc = mft_task_check(ctx, task, "sai2b_get_mft_singularity");
+	if (rc) return rc;
+	const double* s = ctx->h_params.task[task].dbg_sigma;
+	const size_t B = ctx->B;
+	if ((rc = fetch_dbg(ctx, sigma, s, 6))) return rc;
+	if ((rc = fetch_dbg(ctx, alpha, s ? s + 6 * B : nullptr, 1))) return rc;
+	return fetch_dbg(ctx, ns_rank, s ? s + 7 * B : nullptr, 1);
+}
+extern "C" int sai2b_get_model(sai2b_ctx* ctx, int task, double* M, double* J, double* pos, double* rot) {
+	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	int rc;
+	if ((rc = fetch_dbg(ctx, M, ctx->h_params.dbg_M, N * N))) return rc;
+	if (!J && !pos && !rot) return SAI2B_OK;
+	if ((rc = mft_task_check(ctx, task, "sai2b_get_model"))) return rc;
+	const DevTask& d = ctx->h_params.task[task];
+	const size_t B = ctx->B;
+	if ((rc = fetch_dbg(ctx, J, d.dbg_J, 6 * N))) return rc;
+	if ((rc = fetch_dbg(ctx, pos, d.dbg_pose, 3))) return rc;
+	return fetch_dbg(ctx, rot, d.dbg_pose ? d.dbg_pose + 3 * B : nullptr, 9);
+}
+
+extern "C" int sai2b_counters(const sai2b_ctx* ctx, long long* launches, long long* ticks) {
+	if (!ctx) return SAI2B_INVALID_ARGUMENT;
+	if (launches) *launches = ctx->launches;
+	if (ticks) *ticks = ctx->ticks;
+	return SAI2B_OK;
+}

@@ -1,0 +1,136 @@
+// sai2b_kernels.hip — gfx950 kernels of the batched operational-space controller.
+//
+// tick_kernel: one launch = RobotController::updateControllerTaskModels() +
+// computeControlTorques() (reference src/RobotController.cpp:53-74) for B robots, preceded by the
+// model update the reference gets from Sai2Model::updateModel(). One lane per robot, 64-thread
+// workgroups (one wavefront each) so that B/64 workgroups spread over all 1024 SIMDs.
+#include <hip/hip_runtime.h>
+
+#include "sai2b_device.hpp"
+#include "sai2b_launch.h"
+
+namespace sai2b {
+
+template <bool DEBUG>
+__global__ __launch_bounds__(64) void tick_kernel(const DevParams* __restrict__ Pp, int commit_sh, int with_comp,
+													 int do_torque) {
+	const DevParams& P = *Pp;
+	const int B = P.B;
+	const int b = blockIdx.x * 64 + threadIdx.x;
+	if (b >= B) return;
+	RobotCtx rc;
+	UNROLL for (int i = 0; i < N; i++) {
+		rc.q[i] = ld(P.q, i, B, b);
+		rc.dq[i] = ld(P.dq, i, B, b);
+	}
+	real g[N];
+	{
+		// Sai2Model::updateModel(): kinematics, M (CRBA), M^-1 (examples/05-using_robot_controller.cpp:143-145)
+		Frames F;
+		fk(P.model, rc.q, F);
+		real M[N * N];
+		mass_matrix(P.model, F, M);
+		spd_inverse<N>(M, rc.Minv);
+		if (DEBUG && P.dbg_M) {
+			UNROLL for (int i = 0; i < N * N; i++) st(P.dbg_M, i, B, b, M[i]);
+		}
+		// bounded inertia estimate (SingularityHandler.cpp:176-182, JointTask.cpp:254-260), shared by
+		// every task with the same threshold (the reference recomputes it per task: SURVEY App. B-8)
+		bool any_bie = false;
+		real thr = 0;
+		for (int t = 0; t < P.n_tasks; t++)
+			if (P.task[t].decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES) {
+				any_bie = true;
+				thr = P.task[t].bie_threshold;
+			}
+		if (any_bie) {
+			UNROLL for (int i = 0; i < N; i++) M[i * N + i] = fmax(M[i * N + i], thr);
+			spd_inverse<N>(M, rc.MinvB);
+		} else {
+			UNROLL for (int i = 0; i < N * N; i++) rc.MinvB[i] = rc.Minv[i];
+		}
+		if (P.gravity_comp)
+			gravity_vector(P.model, F, g);
+		else {
+			UNROLL for (int i = 0; i < N; i++) g[i] = 0;
+		}
+	}
+	real Nprec[N * N], tau[N];
+	UNROLL for (int i = 0; i < N * N; i++) Nprec[i] = (i % (N + 1) == 0) ? 1.0 : 0.0;
+	UNROLL for (int i = 0; i < N; i++) tau[i] = 0;
+#pragma unroll 1
+	for (int t = 0; t < P.n_tasks; t++) {
+		const DevTask& tk = P.task[t];
+		const bool first = (t == 0), last = (t == P.n_tasks - 1);
+		if (tk.type == SAI2B_MOTION_FORCE_TASK)
+			mft_task<DEBUG>(P, tk, rc, B, b, first, last, commit_sh != 0, do_torque != 0, Nprec, tau);
+		else
+			jt_task<DEBUG>(P, tk, rc, B, b, first, last, with_comp != 0, do_torque != 0, Nprec, tau);
+	}
+	if (do_torque) {
+		UNROLL for (int i = 0; i < N; i++) st(P.tau, i, B, b, tau[i] + g[i]);  // RobotController.cpp:70-72
+	}
+}
+
+// RobotController::reinitializeTasks (RobotController.cpp:76-80): MotionForceTask::reInitializeTask
+// (MotionForceTask.cpp:204-245), SingularityHandler ctor state (SingularityHandler.cpp:53-63),
+// JointTask::reInitializeTask (JointTask.cpp:91-107)
+__global__ __launch_bounds__(64) void reinit_kernel(const DevParams* __restrict__ Pp) {
+	const DevParams& P = *Pp;
+	const int B = P.B;
+	const int b = blockIdx.x * 64 + threadIdx.x;
+	if (b >= B) return;
+	real q[N];
+	UNROLL for (int i = 0; i < N; i++) q[i] = ld(P.q, i, B, b);
+	Frames F;
+	fk(P.model, q, F);
+#pragma unroll 1
+	for (int t = 0; t < P.n_tasks; t++) {
+		const DevTask& tk = P.task[t];
+		if (tk.type == SAI2B_MOTION_FORCE_TASK) {
+			real x[3], R[9];
+			frame_pose(tk, F, x, R);
+			UNROLL for (int k = 0; k < 3; k++) st(tk.goals, k, B, b, x[k]);
+			UNROLL for (int k = 0; k < 9; k++) st(tk.goals, 3 + k, B, b, R[k]);
+			for (int k = 12; k < MFT_GOAL_ROWS; k++) st(tk.goals, k, B, b, 0.0);
+			for (int k = 0; k < 6; k++) st(tk.sensed, k, B, b, 0.0);
+			for (int k = 0; k < 12; k++) st(tk.state, k, B, b, 0.0);
+			UNROLL for (int i = 0; i < N; i++) {
+				st(tk.state, 12 + i, B, b, 0.5 * (P.model.q_lower[i] + P.model.q_upper[i]));
+				st(tk.state, 19 + i, B, b, 0.0);
+				st(tk.state, 26 + i, B, b, 1.0);
+			}
+			for (int k = 0; k < MFT_ISTATE_ROWS; k++) tk.istate[(size_t)k * B + b] = 0;
+		} else {
+			real cur[N];
+			mv<N, N>(tk.S, q, cur);
+			UNROLL for (int i = 0; i < N; i++)
+				if (i < tk.k0) {
+					st(tk.goals, i, B, b, cur[i]);
+					st(tk.goals, tk.k0 + i, B, b, 0.0);
+					st(tk.goals, 2 * tk.k0 + i, B, b, 0.0);
+					st(tk.state, i, B, b, 0.0);
+				}
+		}
+	}
+}
+
+}  // namespace sai2b
+
+extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int debug, int commit_sh, int with_comp,
+								 int do_torque, hipStream_t stream) {
+	const int blocks = (B + 63) / 64;
+	if (debug)
+		hipLaunchKernelGGL(sai2b::tick_kernel<true>, dim3(blocks), dim3(64), 0, stream, d_params, commit_sh, with_comp,
+						   do_torque);
+	else
+		hipLaunchKernelGGL(sai2b::tick_kernel<false>, dim3(blocks), dim3(64), 0, stream, d_params, commit_sh,
+						   with_comp, do_torque);
+	return (int)hipGetLastError();
+}
+
+extern "C" int sai2b_launch_reinit(const sai2b::DevParams* d_params, int B, hipStream_t stream) {
+	const int blocks = (B + 63) / 64;
+	hipLaunchKernelGGL(sai2b::reinit_kernel, dim3(blocks), dim3(64), 0, stream, d_params);
+	return (int)hipGetLastError();
+}

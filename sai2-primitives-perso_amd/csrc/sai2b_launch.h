@@ -1,0 +1,9 @@
+// sai2b_launch.h — launch entry points shared by sai2b_kernels.hip and sai2b_host.cpp
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "sai2b_params.h"
+
+extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int debug, int commit_sh, int with_comp,
+								 int do_torque, hipStream_t stream);
+extern "C" int sai2b_launch_reinit(const sai2b::DevParams* d_params, int B, hipStream_t stream);

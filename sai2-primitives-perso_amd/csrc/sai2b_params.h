@@ -1,0 +1,85 @@
+// sai2b_params.h — device-visible parameter block shared by the host code and the kernels.
+// One block per ctx lives in device memory; every field is batch-uniform, so the kernels read it
+// with scalar loads.
+#pragma once
+#include "../../include/sai2b.h"
+
+namespace sai2b {
+
+constexpr int N = SAI2B_DOF;
+
+// sai2-model subset: constant part of the kinematic/dynamic model
+struct DevModel {
+	double E[N][9];	  // joint frame rotation in the parent link frame (from URDF rpy)
+	double xyz[N][3]; // joint frame origin in the parent link frame
+	double mass[N];
+	double com[N][3];
+	double inertia[N][6]; // ixx iyy izz ixy ixz iyz at the COM, link axes
+	double q_lower[N], q_upper[N], effort[N];
+	double gravity[3];
+};
+
+// batch-uniform task parameters (sai2b_task_config flattened for the device)
+struct DevTask {
+	int type;
+	int decoupling;
+	double bie_threshold;
+	double dt;
+	// JointTask
+	int k0;
+	int full_selection; // S == I
+	double S[N * N];	// rows >= k0 are zero
+	double kp[N], kv[N], ki[N];
+	int use_vsat;
+	double vsat[N];
+	// MotionForceTask
+	int link;
+	double frame_pos[3], frame_rot[9];
+	int full_projection; // P == I
+	double P[36];
+	int rank; // pos_range + ori_range
+	int in_frame;
+	double kp_pos[3], kv_pos[3], ki_pos[3], kp_ori[3], kv_ori[3], ki_ori[3];
+	double kp_f[3], kv_f[3], ki_f[3], kp_m[3], kv_m[3], ki_m[3];
+	double kff_f, kff_m, max_f, max_m;
+	int cl_force, cl_moment, fdim, mdim;
+	double faxis[3], maxis[3];
+	double lin_vsat, ang_vsat;
+	double sensor_rot[9], sensor_pos[3];
+	// SingularityHandler
+	double s_min, s_max, s_abs_tol, type_1_tol, t2_ratio, t2_angle, perturb;
+	int sh_cap;
+	double kp1, kv1, kv2;
+	int enforce_t1, enforce;
+	// device buffers of this task
+	double* goals;	// MFT [30][B]: pos3 rot9 v3 w3 a3 alpha3 f3 m3 ; JT [3*k0][B]: q dq ddq
+	double* sensed; // MFT [6][B]
+	double* state;	// MFT [33][B]: integ pos3 ori3 f3 m3, q_prior7, dq_prior7, t2dir7 ; JT [k0][B]
+	int* istate;	// MFT [12][B]: hist words 0..6, n_types, count, size, c1, c2
+	// optional introspection outputs (NULL unless debug outputs are enabled)
+	double* dbg_tau;	// [7][B]
+	double* dbg_N;		// [49][B] N * N_prec
+	double* dbg_sigma;	// [8][B] sigma0..5, alpha, ns
+	double* dbg_J;		// [42][B] JWorldFrame
+	double* dbg_pose;	// [12][B] pos3 rot9
+};
+
+constexpr int MFT_GOAL_ROWS = 30;
+constexpr int MFT_STATE_ROWS = 33;
+constexpr int MFT_ISTATE_ROWS = 12;
+// istate rows
+constexpr int IS_NTYPES = 7, IS_COUNT = 8, IS_SIZE = 9, IS_C1 = 10, IS_C2 = 11;
+
+struct DevParams {
+	int B;
+	int n_tasks;
+	int gravity_comp;
+	DevModel model;
+	DevTask task[SAI2B_MAX_TASKS];
+	const double* q;  // [7][B]
+	const double* dq; // [7][B]
+	double* tau;	  // [7][B]
+	double* dbg_M;	  // [49][B] or NULL
+};
+
+}  // namespace sai2b

@@ -1,0 +1,131 @@
+"""CPU tests of the product's host-side logic: the C-ABI library loads, exports every symbol that
+include/sai2b.h declares, its configuration helpers agree with the oracle's independent
+restatement, and validation errors mirror the reference's std::invalid_argument conditions.
+No compute entry point is called (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import sai2_primitives_perso_amd as pkg
+from sai2_primitives_perso_amd._abi import TaskConfig, struct_to_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _same(a, b, tol=1e-14):
+    da, db = struct_to_dict(a), struct_to_dict(b)
+    assert da.keys() == db.keys()
+    for k in da:
+        if isinstance(da[k], list):
+            assert np.allclose(da[k], db[k], rtol=0, atol=tol), k
+        else:
+            assert da[k] == db[k], k
+
+
+def test_library_exports_every_declared_symbol():
+    lib = pkg._abi.load_library()
+    header = open(os.path.join(ROOT, "include", "sai2b.h")).read()
+    declared = set(re.findall(r"\b(sai2b_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(pkg._abi.EXPORTS), declared ^ set(pkg._abi.EXPORTS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+
+
+def test_struct_layout_matches_c():
+    """ctypes mirror vs the C compiler's layout, via a tiny probe compiled against the header"""
+    import subprocess
+    import tempfile
+
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "sai2b.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(sai2b_robot_model), sizeof(sai2b_task_config), offsetof(sai2b_task_config, s_min), offsetof(sai2b_task_config, link));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "p.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "p"), os.path.join(d, "p.c")], check=True)
+        out = subprocess.run([os.path.join(d, "p")], capture_output=True, text=True, check=True).stdout.split()
+    assert int(out[0]) == C.sizeof(pkg.RobotModel)
+    assert int(out[1]) == C.sizeof(TaskConfig)
+    assert int(out[2]) == TaskConfig.s_min.offset
+    assert int(out[3]) == TaskConfig.link.offset
+
+
+def test_panda_model_matches_oracle():
+    _same(pkg.panda_model(), ol.panda_model())
+    m = pkg.panda_model()
+    assert abs(m.link_mass[6] - 2.0) < 1e-15  # link7 1.8 kg + end-effector 0.2 kg
+
+
+def test_default_task_configs_match_oracle():
+    _same(pkg.joint_task_config("a"), ol.joint_task("a"))
+    sel = np.zeros((2, 7))
+    sel[0, 0] = sel[1, 6] = 1
+    _same(pkg.joint_task_config("b", sel), ol.joint_task("b", sel))
+    _same(pkg.motion_force_task_config("c"), ol.motion_force_task("c"))
+    rng = np.random.default_rng(0)
+    for dirs in (
+        (np.eye(3), np.zeros((0, 3))),
+        (np.array([[0, 1.0, 0], [0, 0, 1.0]]), np.array([[0, 0, 1.0]])),
+        (rng.normal(size=(2, 3)), rng.normal(size=(3, 3))),
+        (np.array([[1.0, 1, 0], [2.0, 2, 0]]), np.zeros((0, 3))),  # rank-deficient directions
+    ):
+        a = pkg.motion_force_task_config("d", partial=dirs)
+        b = ol.motion_force_task("d", partial=dirs)
+        _same(a, b, tol=1e-13)
+    assert pkg.motion_force_task_config("e", partial=(np.array([[1.0, 1, 0], [2.0, 2, 0]]), np.zeros((0, 3)))).pos_range == 1
+
+
+def test_validation_errors_mirror_reference():
+    lib = pkg._abi.load_library()
+
+    def validate(cfgs):
+        arr = (TaskConfig * len(cfgs))(*cfgs)
+        msg = C.create_string_buffer(256)
+        rc = lib.sai2b_validate_tasks(arr, len(cfgs), msg, 256)
+        return rc, msg.value.decode()
+
+    rc, msg = validate([pkg.joint_task_config("a"), pkg.joint_task_config("b")])
+    assert rc == pkg._abi.INVALID_ARGUMENT and "nullspace of a full joint task" in msg
+    rc, msg = validate([pkg.motion_force_task_config("a"), pkg.joint_task_config("a")])
+    assert rc and "unique names" in msg
+    a, b = pkg.motion_force_task_config("a"), pkg.joint_task_config("b")
+    b.loop_timestep = 0.002
+    rc, msg = validate([a, b])
+    assert rc and "same loop timestep" in msg
+    rc, msg = validate([])
+    assert rc and "at least one task" in msg
+    assert validate([pkg.motion_force_task_config("a"), pkg.joint_task_config("b")])[0] == 0
+    with pytest.raises(ValueError, match="not full rank"):
+        pkg.joint_task_config("a", np.array([[1.0, 0, 0, 0, 0, 0, 0], [2.0, 0, 0, 0, 0, 0, 0]]))
+    with pytest.raises(ValueError, match="cannot both be empty"):
+        pkg.motion_force_task_config("a", partial=(np.zeros((0, 3)), np.zeros((0, 3))))
+    with pytest.raises(ValueError, match="size not consistent"):
+        pkg.joint_task_config("a", np.zeros((2, 6)))
+
+
+def test_create_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        pkg.Controller(pkg.panda_model(), [pkg.joint_task_config("a")], 4)
+
+
+def test_workload_generator_is_deterministic_and_in_range():
+    a = pkg.workloads.make_inputs(3, B=128)
+    b = pkg.workloads.make_inputs(3, B=128)
+    assert np.array_equal(a["q"], b["q"]) and np.array_equal(a["mft0"]["rot"], b["mft0"]["rot"])
+    lo, hi = pkg.workloads.PANDA_LOWER[:, None], pkg.workloads.PANDA_UPPER[:, None]
+    assert (a["q"] > lo).all() and (a["q"] < hi).all()
+    R = a["mft0"]["rot"].T.reshape(-1, 3, 3)
+    assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-12
+    # configs 2/3/5 keep a margin from the singularity-blending threshold
+    J, _, _ = pkg.workloads.frame_jacobian(*pkg.workloads.fk(a["q"].T))
+    s = np.linalg.svd(J, compute_uv=False)
+    assert (s[:, 5] / s[:, 0] >= 0.1).all()
+    # different ranks of a sharded run draw different robots
+    c = pkg.workloads.make_inputs(5, B=64, rank=1)
+    d = pkg.workloads.make_inputs(5, B=64, rank=0)
+    assert not np.array_equal(c["q"], d["q"])
