@@ -185,6 +185,13 @@ def load_library():
             f"{LIB_PATH} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback."
         )
+    # torch (device memory / streams / torch.distributed plumbing) bundles its own HIP runtime with the
+    # same SONAME as /opt/rocm's; two HIP runtimes in one process cannot both own the GPU, so make
+    # sure torch's copy is the one already mapped before libsai2b.so resolves libamdhip64.so.7.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     P = C.POINTER
     dp = P(_d)
