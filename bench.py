@@ -41,7 +41,8 @@ def cpu_baseline(inp, seconds=8.0):
     for t, (kind, _) in enumerate(inp["tasks"]):
         key = f"{kind}{t}"
         sub[key] = {k: np.ascontiguousarray(v[:, :sample]) for k, v in inp[key].items()}
-    cores = len(os.sched_getaffinity(0))
+    # a 1-GPU box shares its host: use at most the 16-core share of one GPU
+    cores = min(len(os.sched_getaffinity(0)), 16)
     res = {}
     for label, threads in (("single", 1), ("all", cores)):
         o = ol.Oracle(ol.panda_model(), ol.task_configs(sub["tasks"]), sample, threads=threads)

@@ -1,0 +1,274 @@
+// sai2b_fast.hpp — SVD-free fast path of the tick for the hierarchies
+//     [full 6-DOF MotionForceTask]                        (BASELINE config 2)
+//     [full 6-DOF MotionForceTask, full JointTask]        (BASELINE configs 3 and 5)
+// taken by a wavefront only when EVERY one of its robots carries a certificate that the
+// SingularityHandler's decision is "fully non-singular" (SingularityHandler.cpp:100-141). In that
+// branch the reference's result does not depend on the singular vectors at all:
+//     tau_mft = J^T ( (J Mb^-1 J^T)^-1 F_unit + F_force )            (U_ns cancels, :307-309)
+//     N       = I - M^-1 J^T (J M^-1 J^T)^-1 J  =  L^-T (w w^T) L^T   with M = L L^T, w ⟂ range(L^-1 J^T)
+// so with a = L^-T w, b = L w the nullspace projector is the rank-one matrix a b^T, and the whole
+// second-level JointTask (JointTask.cpp:218-356) collapses to a handful of dot products:
+//     Jp = N,  range(Jp) = span(a),  R M_partial R^T = a a^T / |a|^4,
+//     R (R^T Jp Mb^-1 Jp^T R)^-1 R^T = a a^T / (beta |a|^4),   beta = b^T Mb^-1 b.
+// The singular values themselves are needed only for the branch decision, which is replaced by a
+// certificate on G = J J^T:  lambda_max(G) <= ub := tr(G^8)^(1/8) <= 6^(1/8) lambda_max(G), and
+// G - s_max^2 ub I positive definite  =>  s_5/s_0 >= s_max (and every s_i/s_0 with it).
+// Robots the certificate cannot vouch for (s_5/s_0 below ~0.067, or anything singular) make their
+// whole wavefront take the generic Jacobi-SVD path, so the results are the reference's in all cases.
+#pragma once
+#include "sai2b_device.hpp"
+
+namespace sai2b {
+
+// Cholesky factor of an SPD n x n matrix: lower L (row-major, upper part untouched) and the
+// reciprocals of its diagonal.
+template <int n>
+DI void chol(const real* A, real* L, real* dinv) {
+	UNROLL for (int j = 0; j < n; j++) {
+		real s = A[j * n + j];
+		UNROLL for (int k = 0; k < j; k++) s = fma(-L[j * n + k], L[j * n + k], s);
+		real r = rsqrt(s);
+		dinv[j] = r;
+		L[j * n + j] = s * r;
+		UNROLL for (int i = j + 1; i < n; i++) {
+			real t = A[i * n + j];
+			UNROLL for (int k = 0; k < j; k++) t = fma(-L[i * n + k], L[j * n + k], t);
+			L[i * n + j] = t * r;
+		}
+	}
+}
+// x <- L^-1 x (forward substitution)
+template <int n>
+DI void solve_lower(const real* L, const real* dinv, real* x) {
+	UNROLL for (int i = 0; i < n; i++) {
+		real t = x[i];
+		UNROLL for (int k = 0; k < i; k++) t = fma(-L[i * n + k], x[k], t);
+		x[i] = t * dinv[i];
+	}
+}
+// x <- L^-T x (back substitution)
+template <int n>
+DI void solve_lower_t(const real* L, const real* dinv, real* x) {
+	UNROLL for (int i = n - 1; i >= 0; i--) {
+		real t = x[i];
+		UNROLL for (int k = i + 1; k < n; k++) t = fma(-L[k * n + i], x[k], t);
+		x[i] = t * dinv[i];
+	}
+}
+
+// Certificate for "s_0 >= s_abs_tol and s_5 / s_0 >= s_max" on the 6 x 7 Jacobian (see header).
+DI bool certify_nonsingular(const real* J, real s_abs_tol, real s_max) {
+	real G[36], G2[36], G4[36];
+	mm_nt_sym<6, N>(J, J, G);
+	mm_nt_sym<6, 6>(G, G, G2);	// G symmetric: G G^T = G^2
+	mm_nt_sym<6, 6>(G2, G2, G4);
+	real t8 = 0;
+	UNROLL for (int i = 0; i < 6; i++) UNROLL for (int j = 0; j <= i; j++) {
+		real v = G4[i * 6 + j] * G4[i * 6 + j];
+		t8 += (i == j) ? v : 2 * v;
+	}
+	const real ub = sqrt(sqrt(sqrt(t8)));  // lambda_max <= ub <= 6^(1/8) lambda_max
+	// s_0^2 = lambda_max >= ub / 6^(1/8)
+	bool ok = ub > 1.2511 * s_abs_tol * s_abs_tol;
+	// LDL^T pivots of G - c I, c slightly above s_max^2 ub
+	const real c = s_max * s_max * ub * (1.0 + 1e-9);
+	const real floor_ = 1e-11 * ub;
+	real Lm[36], d[6];
+	UNROLL for (int j = 0; j < 6; j++) {
+		real s = G[j * 6 + j] - c;
+		UNROLL for (int k = 0; k < j; k++) s = fma(-Lm[j * 6 + k] * Lm[j * 6 + k], d[k], s);
+		d[j] = s;
+		ok = ok && (s > floor_);
+		const real inv = 1.0 / s;
+		UNROLL for (int i = j + 1; i < 6; i++) {
+			real t = G[i * 6 + j];
+			UNROLL for (int k = 0; k < j; k++) t = fma(-Lm[i * 6 + k] * Lm[j * 6 + k], d[k], t);
+			Lm[i * 6 + j] = t * inv;
+		}
+	}
+	return ok;
+}
+
+// The fast tick body. J/x/R/M are the model quantities at rc.q; HAS_JT selects the 2-level form.
+template <bool HAS_JT>
+DI void fast_tick(const DevParams& P, const RobotCtx& rc, const real* J, const real* x, const real* R, const real* M,
+				  int B, int b, bool with_comp, real* tau) {
+	const DevTask& t0 = P.task[0];
+	real Fu[6], Ff[6];
+	mft_law(t0, rc, J, x, R, B, b, true, Fu, Ff);  // MotionForceTask.cpp:278-503
+
+	// bounded inertia estimate shared by the tasks that ask for it (host checks thresholds agree)
+	bool any_bie = t0.decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES;
+	real thr = t0.bie_threshold;
+	if (HAS_JT && P.task[1].decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES) {
+		any_bie = true;
+		thr = P.task[1].bie_threshold;
+	}
+	real LB[N * N], dB[N];
+	if (any_bie) {
+		real MB[N * N];
+		UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) MB[i * N + j] = M[i * N + j];
+		UNROLL for (int i = 0; i < N; i++) MB[i * N + i] = fmax(MB[i * N + i], thr);
+		chol<N>(MB, LB, dB);
+	}
+	real L[N * N], dL[N];
+	chol<N>(M, L, dL);
+
+	// ---- MotionForceTask torques: J^T (Lambda_mod F_unit + F_force)
+	real z[6];
+	UNROLL for (int i = 0; i < 6; i++) z[i] = Fu[i];
+	real Y[N * 6];	// L^-1 J^T, needed for the nullspace when a JointTask follows
+	if (t0.decoupling != SAI2B_IMPEDANCE || HAS_JT) {
+		UNROLL for (int c = 0; c < 6; c++) {
+			real col[N];
+			UNROLL for (int i = 0; i < N; i++) col[i] = J[c * N + i];
+			solve_lower<N>(L, dL, col);
+			UNROLL for (int i = 0; i < N; i++) Y[i * 6 + c] = col[i];
+		}
+	}
+	real A[36];
+	if (t0.decoupling == SAI2B_FULL_DYNAMIC_DECOUPLING || HAS_JT) {
+		UNROLL for (int i = 0; i < 6; i++) UNROLL for (int j = 0; j <= i; j++) {
+			real s = 0;
+			UNROLL for (int l = 0; l < N; l++) s = fma(Y[l * 6 + i], Y[l * 6 + j], s);
+			A[i * 6 + j] = s;
+			A[j * 6 + i] = s;
+		}
+	}
+	real LA[36], dA[6];
+	if (t0.decoupling == SAI2B_FULL_DYNAMIC_DECOUPLING || HAS_JT) chol<6>(A, LA, dA);
+	if (t0.decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES) {
+		real YB[N * 6], AB[36], LAB[36], dAB[6];
+		UNROLL for (int c = 0; c < 6; c++) {
+			real col[N];
+			UNROLL for (int i = 0; i < N; i++) col[i] = J[c * N + i];
+			solve_lower<N>(LB, dB, col);
+			UNROLL for (int i = 0; i < N; i++) YB[i * 6 + c] = col[i];
+		}
+		UNROLL for (int i = 0; i < 6; i++) UNROLL for (int j = 0; j <= i; j++) {
+			real s = 0;
+			UNROLL for (int l = 0; l < N; l++) s = fma(YB[l * 6 + i], YB[l * 6 + j], s);
+			AB[i * 6 + j] = s;
+			AB[j * 6 + i] = s;
+		}
+		chol<6>(AB, LAB, dAB);
+		solve_lower<6>(LAB, dAB, z);
+		solve_lower_t<6>(LAB, dAB, z);
+	} else if (t0.decoupling == SAI2B_FULL_DYNAMIC_DECOUPLING) {
+		solve_lower<6>(LA, dA, z);
+		solve_lower_t<6>(LA, dA, z);
+	}
+	UNROLL for (int i = 0; i < 6; i++) z[i] += Ff[i];
+	real tau_mft[N];
+	mv_t<6, N>(J, z, tau_mft);	// SingularityHandler.cpp:307-309
+	UNROLL for (int i = 0; i < N; i++) tau[i] = tau_mft[i];
+	if (!HAS_JT) return;
+
+	// ---- nullspace of the MotionForceTask as a rank-one projector a b^T
+	const DevTask& t1 = P.task[1];
+	real Z[N * 6];	// Y LA^-T: orthonormal columns spanning range(Y)
+	UNROLL for (int i = 0; i < N; i++) {
+		UNROLL for (int c = 0; c < 6; c++) {
+			real s = Y[i * 6 + c];
+			UNROLL for (int k = 0; k < c; k++) s = fma(-Z[i * 6 + k], LA[c * 6 + k], s);
+			Z[i * 6 + c] = s * dA[c];
+		}
+	}
+	real pd[N];	 // diagonal of the complementary projector I - Z Z^T
+	int ks = 0;
+	real best = -1;
+	UNROLL for (int i = 0; i < N; i++) {
+		real s = 1.0;
+		UNROLL for (int c = 0; c < 6; c++) s = fma(-Z[i * 6 + c], Z[i * 6 + c], s);
+		pd[i] = s;
+		if (s > best) {
+			best = s;
+			ks = i;
+		}
+	}
+	real zk[6];
+	UNROLL for (int c = 0; c < 6; c++) {
+		real s = 0;
+		UNROLL for (int i = 0; i < N; i++) s = (ks == i) ? Z[i * 6 + c] : s;
+		zk[c] = s;
+	}
+	real w[N];
+	const real wn = rsqrt(best);
+	UNROLL for (int i = 0; i < N; i++) {
+		real s = (ks == i) ? 1.0 : 0.0;
+		UNROLL for (int c = 0; c < 6; c++) s = fma(-Z[i * 6 + c], zk[c], s);
+		w[i] = s * wn;
+	}
+	// one Gram-Schmidt clean-up pass against range(Z) keeps w orthogonal to 1e-16
+	{
+		real pz[6];
+		UNROLL for (int c = 0; c < 6; c++) {
+			real s = 0;
+			UNROLL for (int i = 0; i < N; i++) s = fma(Z[i * 6 + c], w[i], s);
+			pz[c] = s;
+		}
+		real nn = 0;
+		UNROLL for (int i = 0; i < N; i++) {
+			real s = w[i];
+			UNROLL for (int c = 0; c < 6; c++) s = fma(-Z[i * 6 + c], pz[c], s);
+			w[i] = s;
+			nn = fma(s, s, nn);
+		}
+		const real rn = rsqrt(nn);
+		UNROLL for (int i = 0; i < N; i++) w[i] *= rn;
+	}
+	real a[N], bb[N];
+	UNROLL for (int i = 0; i < N; i++) a[i] = w[i];
+	solve_lower_t<N>(L, dL, a);	 // a = L^-T w
+	UNROLL for (int i = 0; i < N; i++) {
+		real s = 0;
+		UNROLL for (int k = 0; k <= i; k++) s = fma(L[i * N + k], w[k], s);
+		bb[i] = s;	// b = L w
+	}
+	real na2 = 0;
+	UNROLL for (int i = 0; i < N; i++) na2 = fma(a[i], a[i], na2);
+
+	// ---- JointTask law (JointTask.cpp:299-345), S = I
+	real* S = t1.state;
+	const real* G = t1.goals;
+	real af = 0, aacc = 0;
+	UNROLL for (int i = 0; i < N; i++) {
+		const real qd = ld(G, i, B, b), dqd = ld(G, N + i, B, b), ddqd = ld(G, 2 * N + i, B, b);
+		const real integ = fma(rc.q[i] - qd, t1.dt, ld(S, i, B, b));
+		st(S, i, B, b, integ);
+		real f;
+		if (t1.use_vsat) {
+			const real kvi = gain_pinv(t1.kv[i]);
+			real dv = -t1.kp[i] * kvi * (rc.q[i] - qd) - t1.ki[i] * kvi * integ;
+			dv = fmin(fmax(dv, -t1.vsat[i]), t1.vsat[i]);
+			f = -t1.kv[i] * (rc.dq[i] - dv);
+		} else {
+			f = -t1.kp[i] * (rc.q[i] - qd) - t1.kv[i] * (rc.dq[i] - dqd) - t1.ki[i] * integ;
+		}
+		af = fma(a[i], f, af);
+		aacc = fma(a[i], ddqd, aacc);
+	}
+	if (with_comp) {  // JointTask.cpp:285-292: - Jp^T R M_partial R^T S M^-1 tau_prec
+		real u[N];
+		UNROLL for (int i = 0; i < N; i++) u[i] = tau_mft[i];
+		solve_lower<N>(L, dL, u);
+		solve_lower_t<N>(L, dL, u);
+		UNROLL for (int i = 0; i < N; i++) aacc = fma(-a[i], u[i], aacc);
+	}
+	real coef = aacc / na2;	 // a^T (a a^T / |a|^4) v = (a.v) / |a|^2
+	if (t1.decoupling == SAI2B_FULL_DYNAMIC_DECOUPLING) {
+		coef += af / na2;
+	} else if (t1.decoupling == SAI2B_IMPEDANCE) {
+		coef += af;	 // a^T (a a^T / |a|^2) f
+	} else {
+		real y[N];
+		UNROLL for (int i = 0; i < N; i++) y[i] = bb[i];
+		solve_lower<N>(LB, dB, y);
+		real beta = 0;
+		UNROLL for (int i = 0; i < N; i++) beta = fma(y[i], y[i], beta);
+		coef += af / (beta * na2);
+	}
+	UNROLL for (int i = 0; i < N; i++) tau[i] = fma(bb[i], coef, tau[i]);  // Jp^T x = b (a^T x)
+}
+
+}  // namespace sai2b

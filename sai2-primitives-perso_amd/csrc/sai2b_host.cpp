@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -24,6 +25,7 @@ struct sai2b_ctx {
 	bool introspection = false;
 	bool models_fresh = false;	// update_task_models() ran for the current state
 	bool params_dirty = true;
+	bool no_fast_path = false;	// SAI2B_NO_FAST_PATH=1 in the environment: always run the generic kernel
 	sai2b_robot_model model;
 	sai2b_task_config cfg[SAI2B_MAX_TASKS];
 	DevParams h_params;
@@ -475,6 +477,8 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
 	ctx->B = batch, ctx->T = n_tasks, ctx->device = device;
 	ctx->model = *model;
+	const char* nf = std::getenv("SAI2B_NO_FAST_PATH");
+	ctx->no_fast_path = nf && nf[0] == '1';
 	DevParams& hp = ctx->h_params;
 	std::memset(&hp, 0, sizeof(hp));
 	hp.B = batch, hp.n_tasks = n_tasks;
@@ -663,7 +667,16 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	int rc = upload_params(ctx);
 	if (rc) return rc;
-	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, commit_sh, with_comp, do_torque, ctx->stream))
+	// eligibility of the SVD-free path (sai2b_fast.hpp): [full MFT] or [full MFT, full JT], handling enforced
+	int fast = 0;
+	if (!ctx->no_fast_path && ctx->T <= 2 && ctx->cfg[0].type == SAI2B_MOTION_FORCE_TASK && ctx->h_params.task[0].full_projection &&
+		ctx->h_params.task[0].rank == 6) {
+		if (ctx->T == 1)
+			fast = 1;
+		else if (ctx->cfg[1].type == SAI2B_JOINT_TASK && ctx->h_params.task[1].full_selection)
+			fast = 2;
+	}
+	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, commit_sh, with_comp, do_torque, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
 	ctx->launches++;
 	return SAI2B_OK;
@@ -673,7 +686,7 @@ static int fetch_tau(sai2b_ctx* ctx, double* tau, int on_device) {
 	if (!tau) return SAI2B_OK;
 	HIP_TRY(ctx, hipMemcpyAsync(tau, ctx->tau, (size_t)N * ctx->B * sizeof(double),
 								on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
-	if (!on_device) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // a returned tau is complete, host or device
 	return SAI2B_OK;
 }
 

@@ -7,22 +7,14 @@
 #include <hip/hip_runtime.h>
 
 #include "sai2b_device.hpp"
+#include "sai2b_fast.hpp"
 #include "sai2b_launch.h"
 
 namespace sai2b {
 
+// Generic tick: Jacobi-SVD based, any hierarchy (the reference's control flow, projector form).
 template <bool DEBUG>
-__global__ __launch_bounds__(64) void tick_kernel(const DevParams* __restrict__ Pp, int commit_sh, int with_comp,
-													 int do_torque) {
-	const DevParams& P = *Pp;
-	const int B = P.B;
-	const int b = blockIdx.x * 64 + threadIdx.x;
-	if (b >= B) return;
-	RobotCtx rc;
-	UNROLL for (int i = 0; i < N; i++) {
-		rc.q[i] = ld(P.q, i, B, b);
-		rc.dq[i] = ld(P.dq, i, B, b);
-	}
+DI void generic_tick(const DevParams& P, RobotCtx& rc, int B, int b, int commit_sh, int with_comp, int do_torque) {
 	real g[N];
 	{
 		// Sai2Model::updateModel(): kinematics, M (CRBA), M^-1 (examples/05-using_robot_controller.cpp:143-145)
@@ -72,6 +64,49 @@ __global__ __launch_bounds__(64) void tick_kernel(const DevParams* __restrict__ 
 	}
 }
 
+// FAST = 0: generic only. FAST = 1: hierarchy [full MFT]; FAST = 2: [full MFT, full JT] — the
+// SVD-free path of sai2b_fast.hpp, taken per wavefront when all of its robots are certified
+// non-singular; any other wavefront falls through to the generic path.
+template <bool DEBUG, int FAST>
+__global__ __launch_bounds__(64) void tick_kernel(const DevParams* __restrict__ Pp, int commit_sh, int with_comp,
+													 int do_torque) {
+	const DevParams& P = *Pp;
+	const int B = P.B;
+	const int b = blockIdx.x * 64 + threadIdx.x;
+	if (b >= B) return;
+	RobotCtx rc;
+	UNROLL for (int i = 0; i < N; i++) {
+		rc.q[i] = ld(P.q, i, B, b);
+		rc.dq[i] = ld(P.dq, i, B, b);
+	}
+	if (FAST != 0) {
+		const DevTask& t0 = P.task[0];
+		real J[6 * N], x[3], R[9], M[N * N], g[N];
+		{
+			Frames F;
+			fk(P.model, rc.q, F);
+			frame_pose(t0, F, x, R);
+			jacobian(t0, F, x, J);
+			mass_matrix(P.model, F, M);
+			if (P.gravity_comp)
+				gravity_vector(P.model, F, g);
+			else {
+				UNROLL for (int i = 0; i < N; i++) g[i] = 0;
+			}
+		}
+		const bool ok = certify_nonsingular(J, t0.s_abs_tol, t0.s_max);
+		// leaving a singular region needs the history reset of the generic path
+		const bool clean = t0.istate[(size_t)IS_NTYPES * B + b] == 0;
+		if (__all(ok && clean)) {
+			real tau[N];
+			fast_tick<FAST == 2>(P, rc, J, x, R, M, B, b, with_comp != 0, tau);
+			UNROLL for (int i = 0; i < N; i++) st(P.tau, i, B, b, tau[i] + g[i]);
+			return;
+		}
+	}
+	generic_tick<DEBUG>(P, rc, B, b, commit_sh, with_comp, do_torque);
+}
+
 // RobotController::reinitializeTasks (RobotController.cpp:76-80): MotionForceTask::reInitializeTask
 // (MotionForceTask.cpp:204-245), SingularityHandler ctor state (SingularityHandler.cpp:53-63),
 // JointTask::reInitializeTask (JointTask.cpp:91-107)
@@ -117,15 +152,18 @@ __global__ __launch_bounds__(64) void reinit_kernel(const DevParams* __restrict_
 
 }  // namespace sai2b
 
-extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int debug, int commit_sh, int with_comp,
-								 int do_torque, hipStream_t stream) {
-	const int blocks = (B + 63) / 64;
+extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int debug, int fast, int commit_sh,
+								 int with_comp, int do_torque, hipStream_t stream) {
+	const dim3 grid((B + 63) / 64), block(64);
+	// the fast path produces torques only: introspection and model-only passes use the generic kernel
 	if (debug)
-		hipLaunchKernelGGL(sai2b::tick_kernel<true>, dim3(blocks), dim3(64), 0, stream, d_params, commit_sh, with_comp,
-						   do_torque);
+		hipLaunchKernelGGL((sai2b::tick_kernel<true, 0>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque);
+	else if (fast == 2 && do_torque && commit_sh)
+		hipLaunchKernelGGL((sai2b::tick_kernel<false, 2>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque);
+	else if (fast == 1 && do_torque && commit_sh)
+		hipLaunchKernelGGL((sai2b::tick_kernel<false, 1>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque);
 	else
-		hipLaunchKernelGGL(sai2b::tick_kernel<false>, dim3(blocks), dim3(64), 0, stream, d_params, commit_sh,
-						   with_comp, do_torque);
+		hipLaunchKernelGGL((sai2b::tick_kernel<false, 0>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque);
 	return (int)hipGetLastError();
 }
 

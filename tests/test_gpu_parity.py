@@ -86,6 +86,59 @@ def test_gpu_matches_oracle_on_seeded_batches(config, B):
         assert e[~ok].max() < 1e-6, e[~ok].max()
 
 
+@pytest.mark.parametrize("config,B", [(2, 4096), (3, 8192)])
+def test_fast_path_matches_oracle(config, B):
+    """no introspection -> the SVD-free kernel variant (sai2b_fast.hpp); every robot of these
+    workloads is certified non-singular, so every wavefront takes it"""
+    inp = pkg.workloads.make_inputs(config, B=B, seed=2000 + config)
+    o, g = _pair(inp, introspection=False)
+    ol.load_inputs(o, inp)
+    ol.load_inputs(g, inp)
+    e = _err(g.tick(), o.tick())
+    assert e.max() < TOL, e.max()
+    # and it must agree with the generic (Jacobi-SVD) kernel variant
+    g2 = pkg.Controller(pkg.panda_model(), pkg.task_configs(inp["tasks"]), B, introspection=True)
+    ol.load_inputs(g2, inp)
+    assert _err(g.tick(), g2.tick()).max() < TOL
+
+
+@pytest.mark.parametrize("name", ["c2_mft", "c3_mft_jt", "c3_full_decoupling", "c3_impedance", "c3_gravity_nocomp",
+                                  "c3_velocity_saturation", "c3_integral_3ticks", "c3_force_open_loop",
+                                  "c3_force_closed_loop"])
+def test_fast_path_matches_golden(name):
+    inp, opts, kw, z = cases.load_case(name)
+    _, g = _pair(inp, opts, introspection=False)
+    tau = cases.run_case_on(g, inp, kw, z)
+    assert _err(tau, z["out_tau"]).max() < TOL
+
+
+def test_fast_path_falls_back_per_wavefront():
+    """a batch where some wavefronts contain singular robots: those take the generic path inside
+    the same launch, the others the fast path; every robot must match the oracle"""
+    B = 1024
+    inp = pkg.workloads.make_inputs(3, B=B, seed=41)
+    q = inp["q"].copy()
+    q[3, 70] = -0.08  # wavefront 1: elbow nearly extended
+    q[5, 700] = 0.01  # wavefront 10: wrist nearly aligned
+    q[5, 701] = 0.3   # wavefront 10: inside the certificate's grey zone or plain regular
+    inp["q"] = q
+    o, g = _pair(inp, introspection=False)
+    ol.load_inputs(o, inp)
+    ol.load_inputs(g, inp)
+    for _ in range(3):
+        tau_o, tau_g = o.tick(), g.tick()
+        _, _, ro = o.get_mft_singularity(0)
+        assert (ro < 6).sum() >= 2
+        e = _err(tau_g, tau_o)
+        assert e[ro == 6].max() < TOL
+        assert e.max() < 1e-6
+    # robots leave the singular region: history must be cleared by the generic path, then fast again
+    o.set_state(pkg.workloads.make_inputs(3, B=B, seed=41)["q"], inp["dq"])
+    g.set_state(pkg.workloads.make_inputs(3, B=B, seed=41)["q"], inp["dq"])
+    for _ in range(2):
+        assert _err(g.tick(), o.tick()).max() < TOL
+
+
 def test_fused_tick_equals_split_api_and_is_repeatable():
     inp = pkg.workloads.make_inputs(3, B=1024, seed=77)
     g = pkg.Controller(pkg.panda_model(), pkg.task_configs(inp["tasks"]), inp["B"])
