@@ -118,9 +118,9 @@ def test_fast_path_falls_back_per_wavefront():
     B = 1024
     inp = pkg.workloads.make_inputs(3, B=B, seed=41)
     q = inp["q"].copy()
-    q[3, 70] = -0.08  # wavefront 1: elbow nearly extended
-    q[5, 700] = 0.01  # wavefront 10: wrist nearly aligned
-    q[5, 701] = 0.3   # wavefront 10: inside the certificate's grey zone or plain regular
+    q[3, 64:70] = -0.0715  # wavefront 1: elbow nearly extended
+    q[5, 700:704] = 0.004  # wavefront 10: wrist nearly aligned
+    q[5, 710] = 0.3  # wavefront 11: inside the certificate's grey zone or plain regular
     inp["q"] = q
     o, g = _pair(inp, introspection=False)
     ol.load_inputs(o, inp)
@@ -146,9 +146,13 @@ def test_fused_tick_equals_split_api_and_is_repeatable():
     a = g.tick()
     b = g.tick()
     assert np.array_equal(a, b), "stateless config must be bit-repeatable"
+    # split API: the torque pass after update_task_models() runs the generic (Jacobi-SVD) kernel
+    # variant, the fused tick above the SVD-free one: equal to rounding, not bit for bit
     g.update_task_models()
     c = g.compute_control_torques()
-    assert np.array_equal(a, c)
+    assert _err(c, a).max() < 1e-12
+    g.update_task_models()
+    assert np.array_equal(g.compute_control_torques(), c)
     # device-resident output path
     import torch
 
