@@ -1,0 +1,430 @@
+/*
+ * Sai2PrimitivesBatched.h — header-only C++ facade over the C ABI (sai2b.h) that keeps the
+ * reference's class and method names (reference src/Sai2Primitives.h:1-6 umbrella;
+ * src/RobotController.h:25-40; src/tasks/TemplateTask.h:25-123; src/tasks/JointTask.h:56-384;
+ * src/tasks/MotionForceTask.h:96-753) with every vector/matrix batched.
+ *
+ * Differences from the reference signatures, all forced by batching and by the absence of
+ * Eigen / sai2-model in this build:
+ *   - `std::shared_ptr<Sai2Model::Sai2Model>` becomes `std::shared_ptr<BatchedRobotModel>`
+ *     (constant model + batch size + device; setQ/setDq take [7][B] arrays);
+ *   - Eigen::VectorXd / MatrixXd become `Batch` = std::vector<double> in SoA layout [C][B]
+ *     (component-major, batch-minor; matrices row-major inside the component index);
+ *   - errors: std::invalid_argument for the reference's argument checks, std::runtime_error for HIP.
+ * An Eigen-typed adapter for batch == 1 is a "next" row.
+ */
+#ifndef SAI2_PRIMITIVES_BATCHED_H_
+#define SAI2_PRIMITIVES_BATCHED_H_
+
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "sai2b.h"
+
+namespace Sai2Primitives {
+
+using Batch = std::vector<double>;
+
+// reference src/tasks/TemplateTask.h:19-23
+enum TaskType { UNDEFINED = SAI2B_UNDEFINED, JOINT_TASK = SAI2B_JOINT_TASK, MOTION_FORCE_TASK = SAI2B_MOTION_FORCE_TASK };
+// reference src/helper_modules/Sai2PrimitivesCommonDefinitions.h:9-23
+enum DynamicDecouplingType {
+	FULL_DYNAMIC_DECOUPLING = SAI2B_FULL_DYNAMIC_DECOUPLING,
+	BOUNDED_INERTIA_ESTIMATES = SAI2B_BOUNDED_INERTIA_ESTIMATES,
+	IMPEDANCE = SAI2B_IMPEDANCE
+};
+struct PIDGains {
+	double kp, kv, ki;
+	PIDGains(double kp_, double kv_, double ki_) : kp(kp_), kv(kv_), ki(ki_) {}
+};
+
+namespace detail {
+inline void check(sai2b_ctx* ctx, int rc) {
+	if (rc == SAI2B_OK) return;
+	const char* m = sai2b_last_error(ctx);
+	std::string msg = m ? m : "unknown error";
+	if (rc == SAI2B_INVALID_ARGUMENT) throw std::invalid_argument(msg);
+	throw std::runtime_error(msg);
+}
+}  // namespace detail
+
+class RobotController;
+
+// Stands where the reference takes std::shared_ptr<Sai2Model::Sai2Model>
+class BatchedRobotModel {
+public:
+	explicit BatchedRobotModel(int batch, int device = 0) : _batch(batch), _device(device), _q(7 * (size_t)batch, 0.0), _dq(7 * (size_t)batch, 0.0) {
+		if (batch < 1) throw std::invalid_argument("BatchedRobotModel: batch must be >= 1");
+		detail::check(nullptr, sai2b_panda_model(&_model));
+	}
+	BatchedRobotModel(int batch, const sai2b_robot_model& model, int device = 0) : BatchedRobotModel(batch, device) { _model = model; }
+	int dof() const { return SAI2B_DOF; }
+	int batch() const { return _batch; }
+	int device() const { return _device; }
+	const sai2b_robot_model& model() const { return _model; }
+	// Sai2Model::setQ / setDq: [7][B]
+	void setQ(const Batch& q) { assign(_q, q); }
+	void setDq(const Batch& dq) { assign(_dq, dq); }
+	const Batch& q() const { return _q; }
+	const Batch& dq() const { return _dq; }
+	// Sai2Model::updateModel(): the model update is fused into the tick kernel; this pushes the state
+	inline void updateModel();
+
+private:
+	friend class RobotController;
+	void assign(Batch& dst, const Batch& src) {
+		if (src.size() != dst.size()) throw std::invalid_argument("state must have 7 * batch entries ([7][B])");
+		dst = src;
+	}
+	int _batch, _device;
+	sai2b_robot_model _model;
+	Batch _q, _dq;
+	RobotController* _controller = nullptr;
+};
+
+// reference src/tasks/TemplateTask.h:25-123
+class TemplateTask {
+public:
+	TemplateTask(std::shared_ptr<BatchedRobotModel>& robot, const TaskType task_type) : _robot(robot), _task_type(task_type) {}
+	virtual ~TemplateTask() = default;
+	const std::shared_ptr<BatchedRobotModel>& getConstRobotModel() const { return _robot; }
+	double getLoopTimestep() const { return _cfg.loop_timestep; }
+	TaskType getTaskType() const { return _task_type; }
+	std::string getTaskName() const { return _cfg.name; }
+	// N * N_prec of the last tick, [49][B] (TemplateTask.h:88); needs RobotController::enableIntrospection
+	inline Batch getTaskAndPreviousNullspace() const;
+	void setDynamicDecouplingType(const DynamicDecouplingType type) {
+		_cfg.dynamic_decoupling_type = type;
+		syncConfig();
+	}
+	void setBoundedInertiaEstimateThreshold(const double threshold) {
+		_cfg.bie_threshold = threshold < 0 ? 0 : threshold;	 // JointTask.h:369-375
+		syncConfig();
+	}
+	const sai2b_task_config& config() const { return _cfg; }
+
+protected:
+	friend class RobotController;
+	inline void syncConfig();
+	size_t B() const { return (size_t)_robot->batch(); }
+	void checkRows(const Batch& v, size_t rows, const char* what) const {
+		if (v.size() != rows * B()) throw std::invalid_argument(std::string(what) + " size not consistent with task dof and batch\n");
+	}
+	virtual void flushGoals() = 0;
+	std::shared_ptr<BatchedRobotModel> _robot;
+	TaskType _task_type;
+	sai2b_task_config _cfg;
+	RobotController* _owner = nullptr;
+	int _index = -1;
+};
+
+// reference src/tasks/JointTask.h
+class JointTask : public TemplateTask {
+public:
+	// JointTask.h:56-58 (full) — JointTask.cpp:14-21
+	JointTask(std::shared_ptr<BatchedRobotModel>& robot, const std::string& task_name = "joint_task", const double loop_timestep = 0.001)
+		: TemplateTask(robot, JOINT_TASK) {
+		detail::check(nullptr, sai2b_default_joint_task(&_cfg, task_name.c_str(), 0, nullptr));
+		_cfg.loop_timestep = loop_timestep;
+	}
+	// JointTask.h:72-75 (partial; selection is row-major task_dof x 7) — JointTask.cpp:23-43
+	JointTask(std::shared_ptr<BatchedRobotModel>& robot, const std::vector<double>& joint_selection_matrix, const int task_dof,
+			  const std::string& task_name = "partial_joint_task", const double loop_timestep = 0.001)
+		: TemplateTask(robot, JOINT_TASK) {
+		if (task_dof < 1 || joint_selection_matrix.size() != (size_t)task_dof * SAI2B_DOF)
+			throw std::invalid_argument("joint selection matrix size not consistent with robot dof in JointTask constructor\n");
+		detail::check(nullptr, sai2b_default_joint_task(&_cfg, task_name.c_str(), task_dof, joint_selection_matrix.data()));
+		_cfg.loop_timestep = loop_timestep;
+	}
+	bool isFullJointTask() const { return _cfg.task_dof == SAI2B_DOF; }
+	int getTaskDof() const { return _cfg.task_dof; }
+	// JointTask.h:137-179; [task_dof][B]
+	void setGoalPosition(const Batch& v) {
+		checkRows(v, _cfg.task_dof, "goal position vector");
+		_goal_q = v;
+		flushGoals();
+	}
+	void setGoalVelocity(const Batch& v) {
+		checkRows(v, _cfg.task_dof, "goal velocity vector");
+		_goal_dq = v;
+		flushGoals();
+	}
+	void setGoalAcceleration(const Batch& v) {
+		checkRows(v, _cfg.task_dof, "goal acceleration vector");
+		_goal_ddq = v;
+		flushGoals();
+	}
+	// JointTask.h:234-259
+	void setGains(const double kp, const double kv, const double ki = 0) {
+		if (kp < 0 || kv < 0 || ki < 0) throw std::invalid_argument("gains must be positive or zero in JointTask::setGains\n");
+		for (int i = 0; i < SAI2B_DOF; i++) _cfg.kp[i] = kp, _cfg.kv[i] = kv, _cfg.ki[i] = ki;
+		syncConfig();
+	}
+	std::vector<PIDGains> getGains() const {
+		std::vector<PIDGains> g;
+		for (int i = 0; i < _cfg.task_dof; i++) g.emplace_back(_cfg.kp[i], _cfg.kv[i], _cfg.ki[i]);
+		return g;
+	}
+	void enableVelocitySaturation(const double saturation_velocity) {
+		if (saturation_velocity <= 0) throw std::invalid_argument("saturation velocity must be positive in JointTask::enableVelocitySaturation\n");
+		_cfg.use_velocity_saturation = 1;
+		for (int i = 0; i < SAI2B_DOF; i++) _cfg.saturation_velocity[i] = saturation_velocity;
+		syncConfig();
+	}
+	void disableVelocitySaturation() {
+		_cfg.use_velocity_saturation = 0;
+		syncConfig();
+	}
+	// the internal OTG is a "next" row: desired state == goal state
+	void disableInternalOtg() {}
+
+protected:
+	inline void flushGoals() override;
+	Batch _goal_q, _goal_dq, _goal_ddq;
+};
+
+// reference src/tasks/MotionForceTask.h
+class MotionForceTask : public TemplateTask {
+public:
+	// MotionForceTask.h:96-101 — full 6-DOF task at `link` (0-based moving link) + compliant frame
+	MotionForceTask(std::shared_ptr<BatchedRobotModel>& robot, const int link, const double compliant_frame_pos[3],
+					const double* compliant_frame_rot = nullptr, const std::string& task_name = "motion_force_task",
+					const bool is_force_motion_parametrization_in_compliant_frame = false, const double loop_timestep = 0.001)
+		: TemplateTask(robot, MOTION_FORCE_TASK) {
+		detail::check(nullptr, sai2b_default_motion_force_task(&_cfg, task_name.c_str(), link, compliant_frame_pos, compliant_frame_rot, -1,
+															   nullptr, -1, nullptr));
+		_cfg.parametrization_in_compliant_frame = is_force_motion_parametrization_in_compliant_frame;
+		_cfg.loop_timestep = loop_timestep;
+	}
+	// MotionForceTask.h:103-110 — partial task; directions are row-major n x 3
+	MotionForceTask(std::shared_ptr<BatchedRobotModel>& robot, const int link, const std::vector<double>& controlled_directions_translation,
+					const std::vector<double>& controlled_directions_rotation, const double compliant_frame_pos[3],
+					const double* compliant_frame_rot = nullptr, const std::string& task_name = "partial_motion_force_task",
+					const bool is_force_motion_parametrization_in_compliant_frame = false, const double loop_timestep = 0.001)
+		: TemplateTask(robot, MOTION_FORCE_TASK) {
+		detail::check(nullptr, sai2b_default_motion_force_task(&_cfg, task_name.c_str(), link, compliant_frame_pos, compliant_frame_rot,
+															   (int)controlled_directions_translation.size() / 3, controlled_directions_translation.data(),
+															   (int)controlled_directions_rotation.size() / 3, controlled_directions_rotation.data()));
+		_cfg.parametrization_in_compliant_frame = is_force_motion_parametrization_in_compliant_frame;
+		_cfg.loop_timestep = loop_timestep;
+	}
+	// MotionForceTask.h:211-247; positions/velocities/accelerations [3][B], orientation [9][B] row-major
+	void setGoalPosition(const Batch& v) { set(_g[0], v, 3, "goal position"); }
+	void setGoalOrientation(const Batch& v) { set(_g[1], v, 9, "goal orientation"); }
+	void setGoalLinearVelocity(const Batch& v) { set(_g[2], v, 3, "goal linear velocity"); }
+	void setGoalAngularVelocity(const Batch& v) { set(_g[3], v, 3, "goal angular velocity"); }
+	void setGoalLinearAcceleration(const Batch& v) { set(_g[4], v, 3, "goal linear acceleration"); }
+	void setGoalAngularAcceleration(const Batch& v) { set(_g[5], v, 3, "goal angular acceleration"); }
+	// MotionForceTask.h:590-623
+	void setGoalForce(const Batch& v) { set(_g[6], v, 3, "goal force"); }
+	void setGoalMoment(const Batch& v) { set(_g[7], v, 3, "goal moment"); }
+	// MotionForceTask.cpp:805-828 (sensor-frame values)
+	void updateSensedForceAndMoment(const Batch& f, const Batch& m) {
+		checkRows(f, 3, "sensed force");
+		checkRows(m, 3, "sensed moment");
+		_g[8] = f;
+		_g[9] = m;
+		flushGoals();
+	}
+	// MotionForceTask.h:272-328
+	void setPosControlGains(double kp, double kv, double ki = 0) { gains3(_cfg.kp_pos, _cfg.kv_pos, _cfg.ki_pos, kp, kv, ki, "setPosControlGains"); }
+	void setOriControlGains(double kp, double kv, double ki = 0) { gains3(_cfg.kp_ori, _cfg.kv_ori, _cfg.ki_ori, kp, kv, ki, "setOriControlGains"); }
+	void setForceControlGains(double kp, double kv, double ki) { gains3(_cfg.kp_force, _cfg.kv_force, _cfg.ki_force, kp, kv, ki, "setForceControlGains"); }
+	void setMomentControlGains(double kp, double kv, double ki) { gains3(_cfg.kp_moment, _cfg.kv_moment, _cfg.ki_moment, kp, kv, ki, "setMomentControlGains"); }
+	// MotionForceTask.cpp:830-890
+	void parametrizeForceMotionSpaces(const int force_space_dimension, const double axis[3] = nullptr) {
+		if (force_space_dimension < 0 || force_space_dimension > 3)
+			throw std::invalid_argument("Force space dimension should be between 0 and 3 in MotionForceTask::parametrizeForceMotionSpaces\n");
+		if (force_space_dimension == 1 || force_space_dimension == 2) unitAxis(axis, _cfg.force_axis, "Force or motion axis should be a non singular vector in MotionForceTask::parametrizeForceMotionSpaces\n");
+		_cfg.force_space_dimension = force_space_dimension;
+		syncConfig();
+	}
+	void parametrizeMomentRotMotionSpaces(const int moment_space_dimension, const double axis[3] = nullptr) {
+		if (moment_space_dimension < 0 || moment_space_dimension > 3)
+			throw std::invalid_argument("Moment space dimension should be between 0 and 3 in MotionForceTask::parametrizeMomentRotMotionSpaces\n");
+		if (moment_space_dimension == 1 || moment_space_dimension == 2) unitAxis(axis, _cfg.moment_axis, "Moment or rot motion axis should be a non singular vector in MotionForceTask::parametrizeMomentRotMotionSpaces\n");
+		_cfg.moment_space_dimension = moment_space_dimension;
+		syncConfig();
+	}
+	void setClosedLoopForceControl(const bool on = true) {
+		_cfg.closed_loop_force = on;
+		syncConfig();
+	}
+	void setClosedLoopMomentControl(const bool on = true) {
+		_cfg.closed_loop_moment = on;
+		syncConfig();
+	}
+	void enableVelocitySaturation(const double linear_vel_sat = 0.3, const double angular_vel_sat = M_PI / 3) {
+		if (linear_vel_sat <= 0 || angular_vel_sat <= 0)
+			throw std::invalid_argument("Velocity saturation values should be strictly positive or zero in MotionForceTask::enableVelocitySaturation\n");
+		_cfg.use_velocity_saturation = 1;
+		_cfg.linear_saturation_velocity = linear_vel_sat;
+		_cfg.angular_saturation_velocity = angular_vel_sat;
+		syncConfig();
+	}
+	void disableVelocitySaturation() {
+		_cfg.use_velocity_saturation = 0;
+		syncConfig();
+	}
+	void disableInternalOtg() {}
+	// MotionForceTask.h:669-753 (singularity handling)
+	void setSingularityHandlingBounds(const double s_min, const double s_max) {
+		_cfg.s_min = s_min;
+		_cfg.s_max = s_max;
+		syncConfig();
+	}
+	void enforceType1Strategy(const bool on = true) {
+		_cfg.enforce_type_1_strategy = on;
+		syncConfig();
+	}
+	void enableSingularityHandling(const bool on = true) {
+		_cfg.enforce_handling_strategy = on;
+		syncConfig();
+	}
+	// singular values of the projected Jacobian of the last tick, [6][B] (examples/18 logs these)
+	inline Batch getSigmaValues() const;
+
+protected:
+	inline void flushGoals() override;
+	void set(Batch& dst, const Batch& v, size_t rows, const char* what) {
+		checkRows(v, rows, what);
+		dst = v;
+		flushGoals();
+	}
+	void gains3(double* kp, double* kv, double* ki, double p, double v, double i, const char* fn) {
+		if (p < 0 || v < 0 || i < 0) throw std::invalid_argument(std::string("all gains should be positive or zero in MotionForceTask::") + fn + "\n");
+		for (int k = 0; k < 3; k++) kp[k] = p, kv[k] = v, ki[k] = i;
+		syncConfig();
+	}
+	static void unitAxis(const double* a, double* out, const char* msg) {
+		const double n = a ? std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) : 0.0;
+		if (n < 1e-2) throw std::invalid_argument(msg);
+		for (int k = 0; k < 3; k++) out[k] = a[k] / n;
+	}
+	Batch _g[10];  // pos rot v w a alpha f m sensed_f sensed_m
+};
+
+// reference src/RobotController.{h,cpp}
+class RobotController {
+public:
+	RobotController(std::shared_ptr<BatchedRobotModel>& robot, std::vector<std::shared_ptr<TemplateTask>>& tasks) : _robot(robot) {
+		if (tasks.size() == 0) throw std::invalid_argument("RobotController must have at least one task");
+		std::vector<sai2b_task_config> cfgs;
+		for (auto& task : tasks) {
+			if (task->getConstRobotModel() != _robot) throw std::invalid_argument("All tasks must have the same robot model in RobotController");
+			cfgs.push_back(task->config());
+		}
+		// remaining reference checks (timestep, unique names, full joint task last) happen in sai2b_create
+		_ctx = sai2b_create(&robot->model(), cfgs.data(), (int)cfgs.size(), robot->batch(), robot->device());
+		if (!_ctx) {
+			const std::string msg = sai2b_last_error(nullptr);
+			if (msg.find("HIP") != std::string::npos || msg.find("hip") != std::string::npos) throw std::runtime_error(msg);
+			throw std::invalid_argument(msg);
+		}
+		_tasks = tasks;
+		robot->_controller = this;
+		detail::check(_ctx, sai2b_set_state(_ctx, robot->q().data(), robot->dq().data(), 0));
+		detail::check(_ctx, sai2b_reinitialize(_ctx));	// tasks are constructed at the model's current state
+		for (size_t i = 0; i < _tasks.size(); i++) {
+			_tasks[i]->_owner = this;
+			_tasks[i]->_index = (int)i;
+			_task_names.push_back(_tasks[i]->getTaskName());
+			_tasks[i]->flushGoals();
+		}
+	}
+	~RobotController() {
+		if (_robot) _robot->_controller = nullptr;
+		for (auto& t : _tasks) t->_owner = nullptr;
+		sai2b_destroy(_ctx);
+	}
+	RobotController(const RobotController&) = delete;
+	RobotController& operator=(const RobotController&) = delete;
+
+	void updateControllerTaskModels() { detail::check(_ctx, sai2b_update_task_models(_ctx)); }
+	// [7][B]
+	Batch computeControlTorques() {
+		Batch tau(7 * (size_t)_robot->batch());
+		detail::check(_ctx, sai2b_compute_control_torques(_ctx, tau.data(), 0));
+		return tau;
+	}
+	// updateControllerTaskModels() + computeControlTorques() in one kernel launch
+	Batch tick() {
+		Batch tau(7 * (size_t)_robot->batch());
+		detail::check(_ctx, sai2b_tick(_ctx, tau.data(), 0));
+		return tau;
+	}
+	void enableGravityCompensation(const bool enable_gravity_compensation) {
+		detail::check(_ctx, sai2b_enable_gravity_compensation(_ctx, enable_gravity_compensation));
+	}
+	void enableIntrospection(const bool on = true) { detail::check(_ctx, sai2b_enable_introspection(_ctx, on)); }
+	void reinitializeTasks() { detail::check(_ctx, sai2b_reinitialize(_ctx)); }
+	std::shared_ptr<JointTask> getJointTaskByName(const std::string& task_name) {
+		for (auto& task : _tasks)
+			if (task->getTaskName() == task_name) {
+				if (task->getTaskType() != JOINT_TASK)
+					throw std::invalid_argument("Task " + task_name + " is not a JointTask, and cannot be casted as such in RobotController::GetTaskByName");
+				return std::dynamic_pointer_cast<JointTask>(task);
+			}
+		throw std::invalid_argument("Task " + task_name + " not found in RobotController::GetTaskByName");
+	}
+	std::shared_ptr<MotionForceTask> getMotionForceTaskByName(const std::string& task_name) {
+		for (auto& task : _tasks)
+			if (task->getTaskName() == task_name) {
+				if (task->getTaskType() != MOTION_FORCE_TASK)
+					throw std::invalid_argument("Task " + task_name + " is not a MotionForceTask, and cannot be casted as such in RobotController::GetTaskByName");
+				return std::dynamic_pointer_cast<MotionForceTask>(task);
+			}
+		throw std::invalid_argument("Task " + task_name + " not found in RobotController::GetTaskByName");
+	}
+	const std::vector<std::string>& getTaskNames() const { return _task_names; }
+	sai2b_ctx* ctx() { return _ctx; }
+
+private:
+	std::shared_ptr<BatchedRobotModel> _robot;
+	std::vector<std::shared_ptr<TemplateTask>> _tasks;
+	std::vector<std::string> _task_names;
+	sai2b_ctx* _ctx = nullptr;
+};
+
+// ---- inline members that need RobotController
+inline void BatchedRobotModel::updateModel() {
+	if (_controller) detail::check(_controller->ctx(), sai2b_set_state(_controller->ctx(), _q.data(), _dq.data(), 0));
+}
+inline void TemplateTask::syncConfig() {
+	if (_owner) detail::check(_owner->ctx(), sai2b_update_task_config(_owner->ctx(), _index, &_cfg));
+}
+inline Batch TemplateTask::getTaskAndPreviousNullspace() const {
+	if (!_owner) throw std::invalid_argument("task is not attached to a RobotController");
+	Batch out(49 * B());
+	detail::check(_owner->ctx(), sai2b_get_task_nullspace(_owner->ctx(), _index, out.data()));
+	return out;
+}
+inline Batch MotionForceTask::getSigmaValues() const {
+	if (!_owner) throw std::invalid_argument("task is not attached to a RobotController");
+	Batch out(6 * B());
+	detail::check(_owner->ctx(), sai2b_get_mft_singularity(_owner->ctx(), _index, out.data(), nullptr, nullptr));
+	return out;
+}
+inline void JointTask::flushGoals() {
+	if (!_owner) return;
+	auto p = [](const Batch& b) { return b.empty() ? nullptr : b.data(); };
+	detail::check(_owner->ctx(), sai2b_set_jt_goals(_owner->ctx(), _index, p(_goal_q), p(_goal_dq), p(_goal_ddq), 0));
+	_goal_q.clear(), _goal_dq.clear(), _goal_ddq.clear();
+}
+inline void MotionForceTask::flushGoals() {
+	if (!_owner) return;
+	auto p = [](const Batch& b) { return b.empty() ? nullptr : b.data(); };
+	sai2b_ctx* c = _owner->ctx();
+	detail::check(c, sai2b_set_mft_goals(c, _index, p(_g[0]), p(_g[1]), p(_g[2]), p(_g[3]), p(_g[4]), p(_g[5]), 0));
+	if (!_g[6].empty() || !_g[7].empty()) detail::check(c, sai2b_set_mft_goal_wrench(c, _index, p(_g[6]), p(_g[7]), 0));
+	if (!_g[8].empty() || !_g[9].empty()) detail::check(c, sai2b_set_mft_sensed_wrench(c, _index, p(_g[8]), p(_g[9]), 0));
+	for (auto& b : _g) b.clear();
+}
+
+}  // namespace Sai2Primitives
+
+#endif	// SAI2_PRIMITIVES_BATCHED_H_
