@@ -305,8 +305,41 @@ struct RobotCtx {
 	real Minv[N * N], MinvB[N * N];
 };
 
-DI real ld(const real* p, int row, int B, int b) { return p[(size_t)row * B + b]; }
-DI void st(real* p, int row, int B, int b, real v) { p[(size_t)row * B + b] = v; }
+// Batched arrays are device (global) memory: say so, or pointers read from the parameter block are
+// generic and every access becomes a flat_load/flat_store that also ties up lgkmcnt.
+typedef __attribute__((address_space(1))) real greal;
+typedef __attribute__((address_space(1))) int gint;
+DI real ld(const real* p, int row, int B, int b) { return ((const greal*)p)[(size_t)row * B + b]; }
+DI void st(real* p, int row, int B, int b, real v) { ((greal*)p)[(size_t)row * B + b] = v; }
+DI int ldi(const int* p, int row, int B, int b) { return ((const gint*)p)[(size_t)row * B + b]; }
+DI void sti(int* p, int row, int B, int b, int v) { ((gint*)p)[(size_t)row * B + b] = v; }
+
+// Warm the scalar data cache with the whole parameter block in one burst. The block is read with
+// scalar loads all through the straight-line tick code; caches are invalidated at every dispatch, so
+// without this each first touch of a 64-byte line is an exposed L2 round trip for a wave that has
+// nothing else to run (one wave per SIMD).
+template <int LINES>
+DI void prefetch_params(const void* base) {
+	typedef int v16i __attribute__((ext_vector_type(16)));
+	v16i sink;
+	const char* p = (const char*)base;
+#pragma unroll
+	for (int i = 0; i < LINES; i += 8) {
+		asm volatile(
+			"s_load_dwordx16 %0, %1, 0x0\n\t"
+			"s_load_dwordx16 %0, %1, 0x40\n\t"
+			"s_load_dwordx16 %0, %1, 0x80\n\t"
+			"s_load_dwordx16 %0, %1, 0xc0\n\t"
+			"s_load_dwordx16 %0, %1, 0x100\n\t"
+			"s_load_dwordx16 %0, %1, 0x140\n\t"
+			"s_load_dwordx16 %0, %1, 0x180\n\t"
+			"s_load_dwordx16 %0, %1, 0x1c0\n\t"
+			"s_waitcnt lgkmcnt(0)"
+			: "=&s"(sink)
+			: "s"(p + 64 * i)
+			: "memory");
+	}
+}
 
 // sigma matrices (MotionForceTask.cpp:892-971): sf = sigmaForce / sigmaMoment, sp = sigmaPosition /
 // sigmaOrientation for the 3x3 block `blk` of the partial-task projection
@@ -615,19 +648,19 @@ DI void mft_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B
 	// ---- singularity bookkeeping (SingularityHandler.cpp:230-295) and blended torques (:313-367)
 	int* IS = t.istate;
 	real* S = t.state;
-	const int prev_types = IS[(size_t)IS_NTYPES * B + b];
+	const int prev_types = ldi(IS, IS_NTYPES, B, b);
 	real Ntask[N * N];
 	UNROLL for (int i = 0; i < N * N; i++) Ntask[i] = Nns[i];
 	if (sc == 0) {
 		if (prev_types != 0 && commit_sh) {	 // leaving the singular region: clear history (:239-245)
-			IS[(size_t)IS_NTYPES * B + b] = 0;
-			IS[(size_t)IS_COUNT * B + b] = 0;
-			IS[(size_t)IS_SIZE * B + b] = 0;
-			IS[(size_t)IS_C1 * B + b] = 0;
-			IS[(size_t)IS_C2 * B + b] = 0;
+			sti(IS, IS_NTYPES, B, b, 0);
+			sti(IS, IS_COUNT, B, b, 0);
+			sti(IS, IS_SIZE, B, b, 0);
+			sti(IS, IS_C1, B, b, 0);
+			sti(IS, IS_C2, B, b, 0);
 		}
 	} else {
-		int c1 = IS[(size_t)IS_C1 * B + b], c2 = IS[(size_t)IS_C2 * B + b];
+		int c1 = ldi(IS, IS_C1, B, b), c2 = ldi(IS, IS_C2, B, b);
 		// entering conditions (:233-236); lazily kept only while singular — equivalent to the
 		// reference's every-tick refresh because the first singular tick always overwrites them
 		real qprior[N], t2dir[N];
@@ -677,10 +710,10 @@ DI void mft_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B
 			any1 = any1 || (fabs(m) > t.type_1_tol);
 		}
 		if (commit_sh) {  // history ring (:276-293)
-			int count = IS[(size_t)IS_COUNT * B + b], size = IS[(size_t)IS_SIZE * B + b];
+			int count = ldi(IS, IS_COUNT, B, b), size = ldi(IS, IS_SIZE, B, b);
 			const int cap = t.sh_cap;
 			const int idx = count % cap;
-			int word = IS[(size_t)(idx >> 5) * B + b];
+			int word = ldi(IS, idx >> 5, B, b);
 			const int bit = 1 << (idx & 31);
 			if (size == cap) {
 				if (word & bit)
@@ -697,12 +730,12 @@ DI void mft_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B
 				word &= ~bit;
 				c2++;
 			}
-			IS[(size_t)(idx >> 5) * B + b] = word;
-			IS[(size_t)IS_COUNT * B + b] = (count + 1) % (cap * 32768);
-			IS[(size_t)IS_SIZE * B + b] = size;
-			IS[(size_t)IS_C1 * B + b] = c1;
-			IS[(size_t)IS_C2 * B + b] = c2;
-			IS[(size_t)IS_NTYPES * B + b] = sc;
+			sti(IS, idx >> 5, B, b, word);
+			sti(IS, IS_COUNT, B, b, (count + 1) % (cap * 32768));
+			sti(IS, IS_SIZE, B, b, size);
+			sti(IS, IS_C1, B, b, c1);
+			sti(IS, IS_C2, B, b, c2);
+			sti(IS, IS_NTYPES, B, b, sc);
 		}
 		if (split == 0) {
 			// fully singular: pass the task through (:149-150, :317-318)

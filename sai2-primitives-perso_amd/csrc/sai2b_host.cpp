@@ -26,6 +26,7 @@ struct sai2b_ctx {
 	bool models_fresh = false;	// update_task_models() ran for the current state
 	bool params_dirty = true;
 	bool no_fast_path = false;	// SAI2B_NO_FAST_PATH=1 in the environment: always run the generic kernel
+	int block = 64, prefetch = 1;  // tuning knobs (SAI2B_BLOCK, SAI2B_PREFETCH)
 	sai2b_robot_model model;
 	sai2b_task_config cfg[SAI2B_MAX_TASKS];
 	DevParams h_params;
@@ -479,6 +480,8 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	ctx->model = *model;
 	const char* nf = std::getenv("SAI2B_NO_FAST_PATH");
 	ctx->no_fast_path = nf && nf[0] == '1';
+	if (const char* e = std::getenv("SAI2B_BLOCK")) ctx->block = std::atoi(e) == 256 ? 256 : 64;
+	if (const char* e = std::getenv("SAI2B_PREFETCH")) ctx->prefetch = std::atoi(e) != 0;
 	DevParams& hp = ctx->h_params;
 	std::memset(&hp, 0, sizeof(hp));
 	hp.B = batch, hp.n_tasks = n_tasks;
@@ -676,7 +679,7 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 		else if (ctx->cfg[1].type == SAI2B_JOINT_TASK && ctx->h_params.task[1].full_selection)
 			fast = 2;
 	}
-	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, commit_sh, with_comp, do_torque, ctx->stream))
+	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, commit_sh, with_comp, do_torque, ctx->block, ctx->prefetch, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
 	ctx->launches++;
 	return SAI2B_OK;

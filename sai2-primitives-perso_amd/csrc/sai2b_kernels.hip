@@ -67,12 +67,13 @@ DI void generic_tick(const DevParams& P, RobotCtx& rc, int B, int b, int commit_
 // FAST = 0: generic only. FAST = 1: hierarchy [full MFT]; FAST = 2: [full MFT, full JT] — the
 // SVD-free path of sai2b_fast.hpp, taken per wavefront when all of its robots are certified
 // non-singular; any other wavefront falls through to the generic path.
-template <bool DEBUG, int FAST>
-__global__ __launch_bounds__(64) void tick_kernel(const DevParams* __restrict__ Pp, int commit_sh, int with_comp,
-													 int do_torque) {
+template <bool DEBUG, int FAST, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void tick_kernel(const DevParams* __restrict__ Pp, int commit_sh, int with_comp,
+														int do_torque, int prefetch) {
 	const DevParams& P = *Pp;
+	if (prefetch) prefetch_params<(sizeof(DevParams) - 2 * sizeof(DevTask) + 63) / 64 / 8 * 8>(Pp);
 	const int B = P.B;
-	const int b = blockIdx.x * 64 + threadIdx.x;
+	const int b = blockIdx.x * BLOCK + threadIdx.x;
 	if (b >= B) return;
 	RobotCtx rc;
 	UNROLL for (int i = 0; i < N; i++) {
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(64) void tick_kernel(const DevParams* __restrict__ 
 		}
 		const bool ok = certify_nonsingular(J, t0.s_abs_tol, t0.s_max);
 		// leaving a singular region needs the history reset of the generic path
-		const bool clean = t0.istate[(size_t)IS_NTYPES * B + b] == 0;
+		const bool clean = ldi(t0.istate, IS_NTYPES, B, b) == 0;
 		if (__all(ok && clean)) {
 			real tau[N];
 			fast_tick<FAST == 2>(P, rc, J, x, R, M, B, b, with_comp != 0, tau);
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(64) void reinit_kernel(const DevParams* __restrict_
 				st(tk.state, 19 + i, B, b, 0.0);
 				st(tk.state, 26 + i, B, b, 1.0);
 			}
-			for (int k = 0; k < MFT_ISTATE_ROWS; k++) tk.istate[(size_t)k * B + b] = 0;
+			for (int k = 0; k < MFT_ISTATE_ROWS; k++) sti(tk.istate, k, B, b, 0);
 		} else {
 			real cur[N];
 			mv<N, N>(tk.S, q, cur);
@@ -152,18 +153,28 @@ __global__ __launch_bounds__(64) void reinit_kernel(const DevParams* __restrict_
 
 }  // namespace sai2b
 
+template <bool DEBUG, int FAST>
+static void launch_variant(const sai2b::DevParams* d_params, int B, int block, int prefetch, int commit_sh, int with_comp,
+						   int do_torque, hipStream_t stream) {
+	if (block == 256)
+		hipLaunchKernelGGL((sai2b::tick_kernel<DEBUG, FAST, 256>), dim3((B + 255) / 256), dim3(256), 0, stream, d_params, commit_sh,
+						   with_comp, do_torque, prefetch);
+	else
+		hipLaunchKernelGGL((sai2b::tick_kernel<DEBUG, FAST, 64>), dim3((B + 63) / 64), dim3(64), 0, stream, d_params, commit_sh,
+						   with_comp, do_torque, prefetch);
+}
+
 extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int debug, int fast, int commit_sh,
-								 int with_comp, int do_torque, hipStream_t stream) {
-	const dim3 grid((B + 63) / 64), block(64);
+								 int with_comp, int do_torque, int block, int prefetch, hipStream_t stream) {
 	// the fast path produces torques only: introspection and model-only passes use the generic kernel
 	if (debug)
-		hipLaunchKernelGGL((sai2b::tick_kernel<true, 0>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque);
+		launch_variant<true, 0>(d_params, B, 64, prefetch, commit_sh, with_comp, do_torque, stream);
 	else if (fast == 2 && do_torque && commit_sh)
-		hipLaunchKernelGGL((sai2b::tick_kernel<false, 2>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque);
+		launch_variant<false, 2>(d_params, B, block, prefetch, commit_sh, with_comp, do_torque, stream);
 	else if (fast == 1 && do_torque && commit_sh)
-		hipLaunchKernelGGL((sai2b::tick_kernel<false, 1>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque);
+		launch_variant<false, 1>(d_params, B, block, prefetch, commit_sh, with_comp, do_torque, stream);
 	else
-		hipLaunchKernelGGL((sai2b::tick_kernel<false, 0>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque);
+		launch_variant<false, 0>(d_params, B, 64, prefetch, commit_sh, with_comp, do_torque, stream);
 	return (int)hipGetLastError();
 }
 

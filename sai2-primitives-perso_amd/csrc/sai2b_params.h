@@ -74,12 +74,13 @@ struct DevParams {
 	int B;
 	int n_tasks;
 	int gravity_comp;
-	DevModel model;
-	DevTask task[SAI2B_MAX_TASKS];
+	int pad_;
 	const double* q;  // [7][B]
 	const double* dq; // [7][B]
 	double* tau;	  // [7][B]
 	double* dbg_M;	  // [49][B] or NULL
+	DevModel model;
+	DevTask task[SAI2B_MAX_TASKS];
 };
 
 }  // namespace sai2b
