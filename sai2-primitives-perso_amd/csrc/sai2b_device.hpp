@@ -182,6 +182,27 @@ DI void orientation_error(const real* Rd, const real* Rc, real* e) {
 }
 DI real gain_pinv(real k) { return fabs(k) > 1e-6 ? 1.0 / k : 0.0; }
 
+// sin and cos of a joint angle. Joint angles are bounded (|q| of a few pi at most), so the argument
+// reduction is a two-term Cody-Waite step with FMAs (k * PIO2_HI is exact inside the fma) followed by
+// the classic minimax kernels on [-pi/4, pi/4] (coefficients as in fdlibm's __kernel_sin/__kernel_cos);
+// results agree with libm to 1 ulp without OCML's large-argument (Payne-Hanek) machinery.
+DI void sincos_joint(real x, real* sn, real* cs) {
+	const real kf = rint(x * 0.63661977236758134308);  // 2/pi
+	real r = fma(-kf, 1.57079632679489655800e+00, x);
+	r = fma(-kf, 6.12323399573676603587e-17, r);
+	const real z = r * r;
+	const real ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+										 2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+	const real s0 = fma(r * z, ps, r);
+	const real pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+										 -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+	const real c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
+	const int k = (int)kf;
+	const real s1 = (k & 1) ? c0 : s0, c1 = (k & 1) ? s0 : c0;
+	*sn = (k & 2) ? -s1 : s1;
+	*cs = ((k + 1) & 2) ? -c1 : c1;
+}
+
 // ------------------------------------------------------------------ model (sai2-model subset)
 struct Frames {
 	real R[N][9];
@@ -200,7 +221,7 @@ DI void fk(const DevModel& md, const real* q, Frames& F) {
 			mm<3, 3, 3>(Rp, md.E[i], RE);
 		}
 		real s, c;
-		sincos(q[i], &s, &c);
+		sincos_joint(q[i], &s, &c);
 		UNROLL for (int k = 0; k < 3; k++) {
 			F.R[i][3 * k + 0] = fma(c, RE[3 * k], s * RE[3 * k + 1]);
 			F.R[i][3 * k + 1] = fma(c, RE[3 * k + 1], -s * RE[3 * k]);
@@ -373,8 +394,17 @@ DI void mft_law(const DevTask& t, const RobotCtx& rc, const real* J, const real*
 	mv<3, N>(J, rc.dq, v);
 	mv<3, N>(J + 3 * N, rc.dq, w);
 	real sf[9], sp[9], sm[9], so[9];
-	sigma_pair(t, 0, t.fdim, t.faxis, R, sf, sp);
-	sigma_pair(t, 1, t.mdim, t.maxis, R, sm, so);
+	if (t.in_frame) {
+		sigma_pair(t, 0, t.fdim, t.faxis, R, sf, sp);
+		sigma_pair(t, 1, t.mdim, t.maxis, R, sm, so);
+	} else {  // world-frame parametrisation: the four selection matrices are batch-uniform (host-made)
+		UNROLL for (int i = 0; i < 9; i++) {
+			sf[i] = t.sig[0][i];
+			sp[i] = t.sig[1][i];
+			sm[i] = t.sig[2][i];
+			so[i] = t.sig[3][i];
+		}
+	}
 	const real* G = t.goals;
 	real g_pos[3], g_rot[9], g_v[3], g_w[3], g_a[3], g_al[3], g_f[3], g_m[3];
 	UNROLL for (int k = 0; k < 3; k++) {

@@ -442,6 +442,34 @@ static void fill_dev_task(const sai2b_task_config& c, DevTask& d) {
 	d.cl_force = c.closed_loop_force, d.cl_moment = c.closed_loop_moment;
 	d.fdim = c.force_space_dimension, d.mdim = c.moment_space_dimension;
 	d.lin_vsat = c.linear_saturation_velocity, d.ang_vsat = c.angular_saturation_velocity;
+	// MotionForceTask.cpp:892-971 with rotation = identity (world-frame parametrisation)
+	for (int blk = 0; blk < 2; blk++) {
+		const int dim = blk ? c.moment_space_dimension : c.force_space_dimension;
+		const double* ax = blk ? c.moment_axis : c.force_axis;
+		double Pb[9], A[9], T[9], sf[9], sp[9];
+		for (int i = 0; i < 3; i++)
+			for (int j = 0; j < 3; j++) {
+				Pb[3 * i + j] = c.partial_projection[(3 * blk + i) * 6 + 3 * blk + j];
+				const double aa = ax[i] * ax[j], id = i == j ? 1.0 : 0.0;
+				A[3 * i + j] = dim == 1 ? aa : (dim == 2 ? id - aa : (dim == 3 ? id : 0.0));
+			}
+		auto mul = [](const double* X, const double* Y, bool yt, double* Z) {
+			for (int i = 0; i < 3; i++)
+				for (int j = 0; j < 3; j++) {
+					double v = 0;
+					for (int k = 0; k < 3; k++) v += X[3 * i + k] * (yt ? Y[3 * j + k] : Y[3 * k + j]);
+					Z[3 * i + j] = v;
+				}
+		};
+		mul(Pb, A, false, T);
+		mul(T, Pb, true, sf);
+		if (dim == 3) std::memcpy(sf, Pb, sizeof(sf));
+		for (int i = 0; i < 9; i++) A[i] = (i % 4 == 0 ? 1.0 : 0.0) - sf[i];
+		mul(Pb, A, false, T);
+		mul(T, Pb, true, sp);
+		std::memcpy(d.sig[2 * blk], sf, sizeof(sf));
+		std::memcpy(d.sig[2 * blk + 1], sp, sizeof(sp));
+	}
 	d.s_min = c.s_min, d.s_max = c.s_max, d.s_abs_tol = c.s_abs_tol, d.type_1_tol = c.type_1_tol;
 	d.t2_ratio = c.type_2_torque_ratio, d.t2_angle = c.type_2_angle_threshold, d.perturb = c.perturb_step_size;
 	d.sh_cap = c.sh_buffer_size;

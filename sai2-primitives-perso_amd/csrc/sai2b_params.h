@@ -44,6 +44,7 @@ struct DevTask {
 	double kff_f, kff_m, max_f, max_m;
 	int cl_force, cl_moment, fdim, mdim;
 	double faxis[3], maxis[3];
+	double sig[4][9];  // sigmaForce, sigmaPosition, sigmaMoment, sigmaOrientation when !in_frame
 	double lin_vsat, ang_vsat;
 	double sensor_rot[9], sensor_pos[3];
 	// SingularityHandler
