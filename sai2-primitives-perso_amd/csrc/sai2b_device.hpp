@@ -335,32 +335,6 @@ DI void st(real* p, int row, int B, int b, real v) { ((greal*)p)[(size_t)row * B
 DI int ldi(const int* p, int row, int B, int b) { return ((const gint*)p)[(size_t)row * B + b]; }
 DI void sti(int* p, int row, int B, int b, int v) { ((gint*)p)[(size_t)row * B + b] = v; }
 
-// Warm the scalar data cache with the whole parameter block in one burst. The block is read with
-// scalar loads all through the straight-line tick code; caches are invalidated at every dispatch, so
-// without this each first touch of a 64-byte line is an exposed L2 round trip for a wave that has
-// nothing else to run (one wave per SIMD).
-template <int LINES>
-DI void prefetch_params(const void* base) {
-	typedef int v16i __attribute__((ext_vector_type(16)));
-	v16i sink;
-	const char* p = (const char*)base;
-#pragma unroll
-	for (int i = 0; i < LINES; i += 8) {
-		asm volatile(
-			"s_load_dwordx16 %0, %1, 0x0\n\t"
-			"s_load_dwordx16 %0, %1, 0x40\n\t"
-			"s_load_dwordx16 %0, %1, 0x80\n\t"
-			"s_load_dwordx16 %0, %1, 0xc0\n\t"
-			"s_load_dwordx16 %0, %1, 0x100\n\t"
-			"s_load_dwordx16 %0, %1, 0x140\n\t"
-			"s_load_dwordx16 %0, %1, 0x180\n\t"
-			"s_load_dwordx16 %0, %1, 0x1c0\n\t"
-			"s_waitcnt lgkmcnt(0)"
-			: "=&s"(sink)
-			: "s"(p + 64 * i)
-			: "memory");
-	}
-}
 
 // sigma matrices (MotionForceTask.cpp:892-971): sf = sigmaForce / sigmaMoment, sp = sigmaPosition /
 // sigmaOrientation for the 3x3 block `blk` of the partial-task projection

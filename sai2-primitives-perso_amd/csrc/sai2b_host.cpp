@@ -26,7 +26,7 @@ struct sai2b_ctx {
 	bool models_fresh = false;	// update_task_models() ran for the current state
 	bool params_dirty = true;
 	bool no_fast_path = false;	// SAI2B_NO_FAST_PATH=1 in the environment: always run the generic kernel
-	int block = 64, prefetch = 1;  // tuning knobs (SAI2B_BLOCK, SAI2B_PREFETCH)
+	int* wave_flags = nullptr;	// per-wavefront "needs the generic path" flags of the fast kernel
 	sai2b_robot_model model;
 	sai2b_task_config cfg[SAI2B_MAX_TASKS];
 	DevParams h_params;
@@ -508,8 +508,6 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	ctx->model = *model;
 	const char* nf = std::getenv("SAI2B_NO_FAST_PATH");
 	ctx->no_fast_path = nf && nf[0] == '1';
-	if (const char* e = std::getenv("SAI2B_BLOCK")) ctx->block = std::atoi(e) == 256 ? 256 : 64;
-	if (const char* e = std::getenv("SAI2B_PREFETCH")) ctx->prefetch = std::atoi(e) != 0;
 	DevParams& hp = ctx->h_params;
 	std::memset(&hp, 0, sizeof(hp));
 	hp.B = batch, hp.n_tasks = n_tasks;
@@ -528,6 +526,7 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	if ((rc = dev_alloc(ctx, &ctx->dq, N * Bs))) return rc;
 	if ((rc = dev_alloc(ctx, &ctx->tau, N * Bs))) return rc;
 	hp.q = ctx->q, hp.dq = ctx->dq, hp.tau = ctx->tau;
+	if ((rc = dev_alloc(ctx, &ctx->wave_flags, (Bs + 63) / 64))) return rc;
 	for (int t = 0; t < n_tasks; t++) {
 		ctx->cfg[t] = tasks[t];
 		DevTask& d = hp.task[t];
@@ -707,7 +706,7 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 		else if (ctx->cfg[1].type == SAI2B_JOINT_TASK && ctx->h_params.task[1].full_selection)
 			fast = 2;
 	}
-	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, commit_sh, with_comp, do_torque, ctx->block, ctx->prefetch, ctx->stream))
+	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, commit_sh, with_comp, do_torque, ctx->wave_flags, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
 	ctx->launches++;
 	return SAI2B_OK;

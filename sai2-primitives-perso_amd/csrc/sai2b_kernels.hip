@@ -13,8 +13,20 @@
 namespace sai2b {
 
 // Generic tick: Jacobi-SVD based, any hierarchy (the reference's control flow, projector form).
+// wave_flags != NULL: only wavefronts whose flag is set run (the fallback pass behind tick_fast_kernel).
 template <bool DEBUG>
-DI void generic_tick(const DevParams& P, RobotCtx& rc, int B, int b, int commit_sh, int with_comp, int do_torque) {
+__global__ __launch_bounds__(64) void tick_kernel(const DevParams* __restrict__ Pp, int commit_sh, int with_comp,
+													 int do_torque, const int* __restrict__ wave_flags) {
+	if (wave_flags && ((const gint*)wave_flags)[blockIdx.x] == 0) return;
+	const DevParams& P = *Pp;
+	const int B = P.B;
+	const int b = blockIdx.x * 64 + threadIdx.x;
+	if (b >= B) return;
+	RobotCtx rc;
+	UNROLL for (int i = 0; i < N; i++) {
+		rc.q[i] = ld(P.q, i, B, b);
+		rc.dq[i] = ld(P.dq, i, B, b);
+	}
 	real g[N];
 	{
 		// Sai2Model::updateModel(): kinematics, M (CRBA), M^-1 (examples/05-using_robot_controller.cpp:143-145)
@@ -64,48 +76,44 @@ DI void generic_tick(const DevParams& P, RobotCtx& rc, int B, int b, int commit_
 	}
 }
 
-// FAST = 0: generic only. FAST = 1: hierarchy [full MFT]; FAST = 2: [full MFT, full JT] — the
-// SVD-free path of sai2b_fast.hpp, taken per wavefront when all of its robots are certified
-// non-singular; any other wavefront falls through to the generic path.
-template <bool DEBUG, int FAST, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void tick_kernel(const DevParams* __restrict__ Pp, int commit_sh, int with_comp,
-														int do_torque, int prefetch) {
+// FAST = 1: hierarchy [full MFT]; FAST = 2: [full MFT, full JT] — the SVD-free path of
+// sai2b_fast.hpp. A wavefront runs it only when all of its robots are certified non-singular (and
+// none is leaving a singular region); otherwise it touches no state, raises its flag in wave_flags
+// and the flag-gated generic kernel launched right behind handles that wavefront.
+template <int FAST>
+__global__ __launch_bounds__(64) void tick_fast_kernel(const DevParams* __restrict__ Pp, int with_comp,
+														  int* __restrict__ wave_flags) {
 	const DevParams& P = *Pp;
-	if (prefetch) prefetch_params<(sizeof(DevParams) - 2 * sizeof(DevTask) + 63) / 64 / 8 * 8>(Pp);
 	const int B = P.B;
-	const int b = blockIdx.x * BLOCK + threadIdx.x;
+	const int b = blockIdx.x * 64 + threadIdx.x;
 	if (b >= B) return;
 	RobotCtx rc;
 	UNROLL for (int i = 0; i < N; i++) {
 		rc.q[i] = ld(P.q, i, B, b);
 		rc.dq[i] = ld(P.dq, i, B, b);
 	}
-	if (FAST != 0) {
-		const DevTask& t0 = P.task[0];
-		real J[6 * N], x[3], R[9], M[N * N], g[N];
-		{
-			Frames F;
-			fk(P.model, rc.q, F);
-			frame_pose(t0, F, x, R);
-			jacobian(t0, F, x, J);
-			mass_matrix(P.model, F, M);
-			if (P.gravity_comp)
-				gravity_vector(P.model, F, g);
-			else {
-				UNROLL for (int i = 0; i < N; i++) g[i] = 0;
-			}
-		}
-		const bool ok = certify_nonsingular(J, t0.s_abs_tol, t0.s_max);
-		// leaving a singular region needs the history reset of the generic path
-		const bool clean = ldi(t0.istate, IS_NTYPES, B, b) == 0;
-		if (__all(ok && clean)) {
-			real tau[N];
-			fast_tick<FAST == 2>(P, rc, J, x, R, M, B, b, with_comp != 0, tau);
-			UNROLL for (int i = 0; i < N; i++) st(P.tau, i, B, b, tau[i] + g[i]);
-			return;
+	const DevTask& t0 = P.task[0];
+	const bool clean = ldi(t0.istate, IS_NTYPES, B, b) == 0;
+	real J[6 * N], x[3], R[9], M[N * N], g[N];
+	{
+		Frames F;
+		fk(P.model, rc.q, F);
+		frame_pose(t0, F, x, R);
+		jacobian(t0, F, x, J);
+		mass_matrix(P.model, F, M);
+		if (P.gravity_comp)
+			gravity_vector(P.model, F, g);
+		else {
+			UNROLL for (int i = 0; i < N; i++) g[i] = 0;
 		}
 	}
-	generic_tick<DEBUG>(P, rc, B, b, commit_sh, with_comp, do_torque);
+	const bool ok = certify_nonsingular(J, t0.s_abs_tol, t0.s_max);
+	const bool all_ok = __all(ok && clean);
+	if (threadIdx.x == 0) ((gint*)wave_flags)[blockIdx.x] = all_ok ? 0 : 1;
+	if (!all_ok) return;
+	real tau[N];
+	fast_tick<FAST == 2>(P, rc, J, x, R, M, B, b, with_comp != 0, tau);
+	UNROLL for (int i = 0; i < N; i++) st(P.tau, i, B, b, tau[i] + g[i]);
 }
 
 // RobotController::reinitializeTasks (RobotController.cpp:76-80): MotionForceTask::reInitializeTask
@@ -153,28 +161,21 @@ __global__ __launch_bounds__(64) void reinit_kernel(const DevParams* __restrict_
 
 }  // namespace sai2b
 
-template <bool DEBUG, int FAST>
-static void launch_variant(const sai2b::DevParams* d_params, int B, int block, int prefetch, int commit_sh, int with_comp,
-						   int do_torque, hipStream_t stream) {
-	if (block == 256)
-		hipLaunchKernelGGL((sai2b::tick_kernel<DEBUG, FAST, 256>), dim3((B + 255) / 256), dim3(256), 0, stream, d_params, commit_sh,
-						   with_comp, do_torque, prefetch);
-	else
-		hipLaunchKernelGGL((sai2b::tick_kernel<DEBUG, FAST, 64>), dim3((B + 63) / 64), dim3(64), 0, stream, d_params, commit_sh,
-						   with_comp, do_torque, prefetch);
-}
-
 extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int debug, int fast, int commit_sh,
-								 int with_comp, int do_torque, int block, int prefetch, hipStream_t stream) {
+								 int with_comp, int do_torque, int* wave_flags, hipStream_t stream) {
+	const dim3 grid((B + 63) / 64), block(64);
 	// the fast path produces torques only: introspection and model-only passes use the generic kernel
-	if (debug)
-		launch_variant<true, 0>(d_params, B, 64, prefetch, commit_sh, with_comp, do_torque, stream);
-	else if (fast == 2 && do_torque && commit_sh)
-		launch_variant<false, 2>(d_params, B, block, prefetch, commit_sh, with_comp, do_torque, stream);
-	else if (fast == 1 && do_torque && commit_sh)
-		launch_variant<false, 1>(d_params, B, block, prefetch, commit_sh, with_comp, do_torque, stream);
-	else
-		launch_variant<false, 0>(d_params, B, 64, prefetch, commit_sh, with_comp, do_torque, stream);
+	if (debug) {
+		hipLaunchKernelGGL((sai2b::tick_kernel<true>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, nullptr);
+	} else if (fast != 0 && do_torque && commit_sh) {
+		if (fast == 2)
+			hipLaunchKernelGGL((sai2b::tick_fast_kernel<2>), grid, block, 0, stream, d_params, with_comp, wave_flags);
+		else
+			hipLaunchKernelGGL((sai2b::tick_fast_kernel<1>), grid, block, 0, stream, d_params, with_comp, wave_flags);
+		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, wave_flags);
+	} else {
+		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, nullptr);
+	}
 	return (int)hipGetLastError();
 }
 

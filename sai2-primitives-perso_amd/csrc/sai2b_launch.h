@@ -5,5 +5,5 @@
 #include "sai2b_params.h"
 
 extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int debug, int fast, int commit_sh,
-								 int with_comp, int do_torque, int block, int prefetch, hipStream_t stream);
+								 int with_comp, int do_torque, int* wave_flags, hipStream_t stream);
 extern "C" int sai2b_launch_reinit(const sai2b::DevParams* d_params, int B, hipStream_t stream);
