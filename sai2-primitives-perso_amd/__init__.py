@@ -3,7 +3,7 @@
 Host-side mirror of the sai2-primitives RobotController / MotionForceTask / JointTask API over the
 C ABI of include/sai2b.h, whose implementation is hand-written HIP (csrc/). See DESIGN.md.
 """
-from . import _abi, workloads  # noqa: F401
+from . import _abi, sharding, workloads  # noqa: F401
 from ._abi import (  # noqa: F401
     BOUNDED_INERTIA_ESTIMATES,
     DOF,
