@@ -360,13 +360,75 @@ DI void sigma_pair(const DevTask& t, int blk, int dim, const real* axis, const r
 	mm_nt<3, 3, 3>(T, Pb, sp);
 }
 
+// Per-robot inputs of the MotionForceTask law: goals, sensed wrench, integrator state. Loaded in one
+// burst (mft_load) so a caller can issue the loads long before the law consumes them.
+struct MftIn {
+	real g_pos[3], g_rot[9], g_v[3], g_w[3], g_a[3], g_al[3], g_f[3], g_m[3], s_f[3], s_m[3];
+	real integ[12];	 // pos 3, ori 3, force 3, moment 3
+};
+DI void mft_load(const DevTask& t, int B, int b, MftIn& in) {
+	const real* G = t.goals;
+	UNROLL for (int k = 0; k < 3; k++) {
+		in.g_pos[k] = ld(G, k, B, b);
+		in.g_v[k] = ld(G, 12 + k, B, b);
+		in.g_w[k] = ld(G, 15 + k, B, b);
+		in.g_a[k] = ld(G, 18 + k, B, b);
+		in.g_al[k] = ld(G, 21 + k, B, b);
+		in.g_f[k] = in.g_m[k] = in.s_f[k] = in.s_m[k] = 0;
+	}
+	UNROLL for (int k = 0; k < 9; k++) in.g_rot[k] = ld(G, 3 + k, B, b);
+	UNROLL for (int k = 0; k < 6; k++) in.integ[k] = ld(t.state, k, B, b);
+	UNROLL for (int k = 6; k < 12; k++) in.integ[k] = 0;
+	if ((t.fdim | t.mdim) != 0) {  // batch-uniform
+		UNROLL for (int k = 0; k < 3; k++) {
+			in.g_f[k] = ld(G, 24 + k, B, b);
+			in.g_m[k] = ld(G, 27 + k, B, b);
+		}
+		if (t.cl_force || t.cl_moment) {
+			UNROLL for (int k = 0; k < 3; k++) {
+				in.s_f[k] = ld(t.sensed, k, B, b);
+				in.s_m[k] = ld(t.sensed, 3 + k, B, b);
+			}
+			UNROLL for (int k = 6; k < 12; k++) in.integ[k] = ld(t.state, k, B, b);
+		}
+	}
+}
+
+// integrators advance on every torque computation, even with ki = 0 (MotionForceTask.cpp:411-413,446);
+// the force/moment ones only in closed-loop mode (:329-331,359-361)
+DI void mft_store_integrators(const DevTask& t, int B, int b, const MftIn& in) {
+	UNROLL for (int k = 0; k < 6; k++) st(t.state, k, B, b, in.integ[k]);
+	if (t.cl_force) {
+		UNROLL for (int k = 6; k < 9; k++) st(t.state, k, B, b, in.integ[k]);
+	}
+	if (t.cl_moment) {
+		UNROLL for (int k = 9; k < 12; k++) st(t.state, k, B, b, in.integ[k]);
+	}
+}
+
 // MotionForceTask::computeTorques() control law up to the task forces (MotionForceTask.cpp:278-503).
 // Produces F_unit (unit-mass motion force) and F_force (force-related terms + feed-forward).
-DI void mft_law(const DevTask& t, const RobotCtx& rc, const real* J, const real* x, const real* R, int B, int b,
-				bool commit, real* Fu, real* Ff) {
+// The integrators in `in.integ` are advanced in place; mft_store_integrators() writes them back.
+DI void mft_law(const DevTask& t, const RobotCtx& rc, const real* J, const real* x, const real* R, MftIn& in, real* Fu,
+				real* Ff) {
 	real v[3], w[3];
 	mv<3, N>(J, rc.dq, v);
 	mv<3, N>(J + 3 * N, rc.dq, w);
+	if (t.plain_motion) {
+		// full task, no force space, world-frame gains, no velocity saturation: sigma_position =
+		// sigma_orientation = I, sigma_force = sigma_moment = 0 (MotionForceTask.cpp:431-436,463-467)
+		real oe[3];
+		orientation_error(in.g_rot, R, oe);
+		UNROLL for (int k = 0; k < 3; k++) {
+			const real ex = x[k] - in.g_pos[k];
+			in.integ[k] = fma(ex, t.dt, in.integ[k]);
+			in.integ[3 + k] = fma(oe[k], t.dt, in.integ[3 + k]);
+			Fu[k] = in.g_a[k] - t.kp_pos[k] * ex - t.kv_pos[k] * (v[k] - in.g_v[k]) - t.ki_pos[k] * in.integ[k];
+			Fu[3 + k] = in.g_al[k] - t.kp_ori[k] * oe[k] - t.kv_ori[k] * (w[k] - in.g_w[k]) - t.ki_ori[k] * in.integ[3 + k];
+			Ff[k] = Ff[3 + k] = 0;
+		}
+		return;
+	}
 	real sf[9], sp[9], sm[9], so[9];
 	if (t.in_frame) {
 		sigma_pair(t, 0, t.fdim, t.faxis, R, sf, sp);
@@ -379,47 +441,29 @@ DI void mft_law(const DevTask& t, const RobotCtx& rc, const real* J, const real*
 			so[i] = t.sig[3][i];
 		}
 	}
-	const real* G = t.goals;
-	real g_pos[3], g_rot[9], g_v[3], g_w[3], g_a[3], g_al[3], g_f[3], g_m[3];
-	UNROLL for (int k = 0; k < 3; k++) {
-		g_pos[k] = ld(G, k, B, b);
-		g_v[k] = ld(G, 12 + k, B, b);
-		g_w[k] = ld(G, 15 + k, B, b);
-		g_a[k] = ld(G, 18 + k, B, b);
-		g_al[k] = ld(G, 21 + k, B, b);
-	}
-	UNROLL for (int k = 0; k < 9; k++) g_rot[k] = ld(G, 3 + k, B, b);
+	const real *g_pos = in.g_pos, *g_rot = in.g_rot, *g_v = in.g_v, *g_w = in.g_w, *g_a = in.g_a, *g_al = in.g_al;
 	const bool uses_force = (t.fdim | t.mdim) != 0;	 // batch-uniform
 	real gf[3] = {0, 0, 0}, gm[3] = {0, 0, 0}, fs_w[3] = {0, 0, 0}, ms_w[3] = {0, 0, 0};
 	if (uses_force) {
-		UNROLL for (int k = 0; k < 3; k++) {
-			g_f[k] = ld(G, 24 + k, B, b);
-			g_m[k] = ld(G, 27 + k, B, b);
-		}
 		if (t.in_frame) {  // getGoalForce / getGoalMoment (MotionForceTask.cpp:755-769)
-			mv3(R, g_f, gf);
-			mv3(R, g_m, gm);
+			mv3(R, in.g_f, gf);
+			mv3(R, in.g_m, gm);
 		} else {
 			UNROLL for (int k = 0; k < 3; k++) {
-				gf[k] = g_f[k];
-				gm[k] = g_m[k];
+				gf[k] = in.g_f[k];
+				gm[k] = in.g_m[k];
 			}
 		}
 		if (t.cl_force || t.cl_moment) {  // updateSensedForceAndMoment (MotionForceTask.cpp:805-828)
-			real s_f[3], s_m[3], fc[3], mc[3], tmp[3];
-			UNROLL for (int k = 0; k < 3; k++) {
-				s_f[k] = ld(t.sensed, k, B, b);
-				s_m[k] = ld(t.sensed, 3 + k, B, b);
-			}
-			mv3(t.sensor_rot, s_f, fc);
-			mv3(t.sensor_rot, s_m, mc);
+			real fc[3], mc[3], tmp[3];
+			mv3(t.sensor_rot, in.s_f, fc);
+			mv3(t.sensor_rot, in.s_m, mc);
 			cross3(t.sensor_pos, fc, tmp);
 			UNROLL for (int k = 0; k < 3; k++) mc[k] += tmp[k];
 			mv3(R, fc, fs_w);
 			mv3(R, mc, ms_w);
 		}
 	}
-	real* S = t.state;
 	const real dt = t.dt;
 	real f_force[3], f_moment[3], e[3], y[3];
 	// force (MotionForceTask.cpp:327-354); POPC disabled -> vcl - kv vr (POPCExplicitForceControl.cpp:33-35)
@@ -428,8 +472,8 @@ DI void mft_law(const DevTask& t, const RobotCtx& rc, const real* J, const real*
 		UNROLL for (int k = 0; k < 3; k++) e[k] = fs_w[k] - gf[k];
 		mv3(sf, e, y);
 		UNROLL for (int k = 0; k < 3; k++) {
-			integ[k] = fma(y[k], dt, ld(S, 6 + k, B, b));
-			if (commit) st(S, 6 + k, B, b, integ[k]);
+			integ[k] = fma(y[k], dt, in.integ[6 + k]);
+			in.integ[6 + k] = integ[k];
 			e[k] = -t.kp_f[k] * (fs_w[k] - gf[k]) - t.ki_f[k] * integ[k];
 		}
 		mv3(sf, e, fb);
@@ -450,8 +494,8 @@ DI void mft_law(const DevTask& t, const RobotCtx& rc, const real* J, const real*
 		UNROLL for (int k = 0; k < 3; k++) e[k] = ms_w[k] - gm[k];
 		mv3(sm, e, y);
 		UNROLL for (int k = 0; k < 3; k++) {
-			integ[k] = fma(y[k], dt, ld(S, 9 + k, B, b));
-			if (commit) st(S, 9 + k, B, b, integ[k]);
+			integ[k] = fma(y[k], dt, in.integ[9 + k]);
+			in.integ[9 + k] = integ[k];
 			e[k] = -t.kp_m[k] * (ms_w[k] - gm[k]) - t.ki_m[k] * integ[k];
 		}
 		mv3(sm, e, fb);
@@ -470,8 +514,8 @@ DI void mft_law(const DevTask& t, const RobotCtx& rc, const real* J, const real*
 	UNROLL for (int k = 0; k < 3; k++) e[k] = x[k] - g_pos[k];
 	mv3(sp, e, y);
 	UNROLL for (int k = 0; k < 3; k++) {
-		ip[k] = fma(y[k], dt, ld(S, k, B, b));
-		if (commit) st(S, k, B, b, ip[k]);
+		ip[k] = fma(y[k], dt, in.integ[k]);
+		in.integ[k] = ip[k];
 	}
 	if (t.use_vsat) {
 		UNROLL for (int k = 0; k < 3; k++) {
@@ -493,8 +537,8 @@ DI void mft_law(const DevTask& t, const RobotCtx& rc, const real* J, const real*
 	orientation_error(g_rot, R, oe);
 	mv3(so, oe, step);
 	UNROLL for (int k = 0; k < 3; k++) {
-		io[k] = fma(step[k], dt, ld(S, 3 + k, B, b));
-		if (commit) st(S, 3 + k, B, b, io[k]);
+		io[k] = fma(step[k], dt, in.integ[3 + k]);
+		in.integ[3 + k] = io[k];
 	}
 	if (t.use_vsat) {
 		UNROLL for (int k = 0; k < 3; k++) {
@@ -640,7 +684,12 @@ DI void mft_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B
 	}
 	// ---- control law
 	real Fu[6], Ff[6];
-	mft_law(t, rc, J, x, R, B, b, do_torque, Fu, Ff);
+	{
+		MftIn in;
+		mft_load(t, B, b, in);
+		mft_law(t, rc, J, x, R, in, Fu, Ff);
+		if (do_torque) mft_store_integrators(t, B, b, in);
+	}
 	real tau[N];
 	{
 		real a6[6], b6[6];

@@ -90,60 +90,63 @@ DI bool certify_nonsingular(const real* J, real s_abs_tol, real s_max) {
 }
 
 // The fast tick body. J/x/R/M are the model quantities at rc.q; HAS_JT selects the 2-level form.
+// Ordered to keep few matrices alive at once: law -> nullspace vectors (a, b) -> MFT torques -> JT.
+// Inputs of the second-level JointTask law after the early part (fast_jt_early): the PD(+I) unit
+// torques f, the goal accelerations, and the advanced integrators (stored once the wavefront is
+// committed to the fast path).
+struct JtEarly {
+	real f[N], ddq[N], integ[N];
+};
+DI void fast_jt_early(const DevTask& t1, const RobotCtx& rc, int B, int b, JtEarly& e) {
+	const real* G = t1.goals;
+	UNROLL for (int i = 0; i < N; i++) {  // JointTask.cpp:299-345, S = I
+		const real qd = ld(G, i, B, b), dqd = ld(G, N + i, B, b);
+		e.ddq[i] = ld(G, 2 * N + i, B, b);
+		const real integ = fma(rc.q[i] - qd, t1.dt, ld(t1.state, i, B, b));
+		e.integ[i] = integ;
+		if (t1.use_vsat) {
+			const real kvi = gain_pinv(t1.kv[i]);
+			real dv = -t1.kp[i] * kvi * (rc.q[i] - qd) - t1.ki[i] * kvi * integ;
+			dv = fmin(fmax(dv, -t1.vsat[i]), t1.vsat[i]);
+			e.f[i] = -t1.kv[i] * (rc.dq[i] - dv);
+		} else {
+			e.f[i] = -t1.kp[i] * (rc.q[i] - qd) - t1.kv[i] * (rc.dq[i] - dqd) - t1.ki[i] * integ;
+		}
+	}
+}
+
+#define SAI2B_PHASE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("; SAI2B_PHASE_MARK"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
 template <bool HAS_JT>
-DI void fast_tick(const DevParams& P, const RobotCtx& rc, const real* J, const real* x, const real* R, const real* M,
-				  int B, int b, bool with_comp, real* tau) {
+DI void fast_tick(const DevParams& P, const real* J, const real* M, const real* Fu, const real* Ff, int B, int b,
+				  bool with_comp, const JtEarly& jt, real* tau) {
 	const DevTask& t0 = P.task[0];
-	real Fu[6], Ff[6];
-	mft_law(t0, rc, J, x, R, B, b, true, Fu, Ff);  // MotionForceTask.cpp:278-503
 
 	// bounded inertia estimate shared by the tasks that ask for it (host checks thresholds agree)
-	bool any_bie = t0.decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES;
+	const bool mft_bie = t0.decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES;
+	const bool mft_full = t0.decoupling == SAI2B_FULL_DYNAMIC_DECOUPLING;
+	bool any_bie = mft_bie;
 	real thr = t0.bie_threshold;
 	if (HAS_JT && P.task[1].decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES) {
 		any_bie = true;
 		thr = P.task[1].bie_threshold;
 	}
-	real LB[N * N], dB[N];
+	// Phase A: bounded-inertia side (LB, YB = LB^-1 J^T, AB = YB^T YB, z = AB^-1 F_unit); YB dies here
+	real LB[N * N], dB[N], z[6];
+	UNROLL for (int i = 0; i < 6; i++) z[i] = Fu[i];
 	if (any_bie) {
 		real MB[N * N];
 		UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) MB[i * N + j] = M[i * N + j];
 		UNROLL for (int i = 0; i < N; i++) MB[i * N + i] = fmax(MB[i * N + i], thr);
 		chol<N>(MB, LB, dB);
 	}
-	real L[N * N], dL[N];
-	chol<N>(M, L, dL);
-
-	// ---- MotionForceTask torques: J^T (Lambda_mod F_unit + F_force)
-	real z[6];
-	UNROLL for (int i = 0; i < 6; i++) z[i] = Fu[i];
-	real Y[N * 6];	// L^-1 J^T, needed for the nullspace when a JointTask follows
-	if (t0.decoupling != SAI2B_IMPEDANCE || HAS_JT) {
-		UNROLL for (int c = 0; c < 6; c++) {
-			real col[N];
-			UNROLL for (int i = 0; i < N; i++) col[i] = J[c * N + i];
-			solve_lower<N>(L, dL, col);
-			UNROLL for (int i = 0; i < N; i++) Y[i * 6 + c] = col[i];
-		}
-	}
-	real A[36];
-	if (t0.decoupling == SAI2B_FULL_DYNAMIC_DECOUPLING || HAS_JT) {
-		UNROLL for (int i = 0; i < 6; i++) UNROLL for (int j = 0; j <= i; j++) {
-			real s = 0;
-			UNROLL for (int l = 0; l < N; l++) s = fma(Y[l * 6 + i], Y[l * 6 + j], s);
-			A[i * 6 + j] = s;
-			A[j * 6 + i] = s;
-		}
-	}
-	real LA[36], dA[6];
-	if (t0.decoupling == SAI2B_FULL_DYNAMIC_DECOUPLING || HAS_JT) chol<6>(A, LA, dA);
-	if (t0.decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES) {
+	if (mft_bie) {	// Lambda_mod = (J Mb^-1 J^T)^-1
 		real YB[N * 6], AB[36], LAB[36], dAB[6];
 		UNROLL for (int c = 0; c < 6; c++) {
-			real col[N];
-			UNROLL for (int i = 0; i < N; i++) col[i] = J[c * N + i];
-			solve_lower<N>(LB, dB, col);
-			UNROLL for (int i = 0; i < N; i++) YB[i * 6 + c] = col[i];
+			real colb[N];
+			UNROLL for (int i = 0; i < N; i++) colb[i] = J[c * N + i];
+			solve_lower<N>(LB, dB, colb);
+			UNROLL for (int i = 0; i < N; i++) YB[i * 6 + c] = colb[i];
 		}
 		UNROLL for (int i = 0; i < 6; i++) UNROLL for (int j = 0; j <= i; j++) {
 			real s = 0;
@@ -154,104 +157,110 @@ DI void fast_tick(const DevParams& P, const RobotCtx& rc, const real* J, const r
 		chol<6>(AB, LAB, dAB);
 		solve_lower<6>(LAB, dAB, z);
 		solve_lower_t<6>(LAB, dAB, z);
-	} else if (t0.decoupling == SAI2B_FULL_DYNAMIC_DECOUPLING) {
-		solve_lower<6>(LA, dA, z);
-		solve_lower_t<6>(LA, dA, z);
 	}
+	SAI2B_PHASE();
+	// Phase B: M = L L^T, Y = L^-1 J^T; from here J and M are dead: tau_mft = J^T z = L (Y z)
+	real L[N * N], dL[N], Y[N * 6];
+	chol<N>(M, L, dL);
+	UNROLL for (int c = 0; c < 6; c++) {
+		real col[N];
+		UNROLL for (int i = 0; i < N; i++) col[i] = J[c * N + i];
+		solve_lower<N>(L, dL, col);
+		UNROLL for (int i = 0; i < N; i++) Y[i * 6 + c] = col[i];
+	}
+	SAI2B_PHASE();
+	// ---- A = J M^-1 J^T = Y^T Y and its factor: Lambda for FULL decoupling, nullspace for the JT
+	real a[N], bb[N], na2 = 0;
+	if (HAS_JT || mft_full) {
+		real A[36], LA[36], dA[6];
+		UNROLL for (int i = 0; i < 6; i++) UNROLL for (int j = 0; j <= i; j++) {
+			real s = 0;
+			UNROLL for (int l = 0; l < N; l++) s = fma(Y[l * 6 + i], Y[l * 6 + j], s);
+			A[i * 6 + j] = s;
+			A[j * 6 + i] = s;
+		}
+		chol<6>(A, LA, dA);
+		if (mft_full) {	 // Lambda_mod = Lambda = A^-1
+			solve_lower<6>(LA, dA, z);
+			solve_lower_t<6>(LA, dA, z);
+		}
+		if (HAS_JT) {
+			// w = unit vector orthogonal to range(Y): the row k of the complementary projector
+			// I - Y A^-1 Y^T with the largest diagonal, normalised
+			real tk[6], best = -1;
+			int ks = 0;
+			UNROLL for (int c = 0; c < 6; c++) tk[c] = 0;
+			UNROLL for (int i = 0; i < N; i++) {
+				real t[6];
+				UNROLL for (int c = 0; c < 6; c++) t[c] = Y[i * 6 + c];
+				solve_lower<6>(LA, dA, t);
+				real pd = 1.0;
+				UNROLL for (int c = 0; c < 6; c++) pd = fma(-t[c], t[c], pd);
+				const bool take = pd > best;
+				best = take ? pd : best;
+				ks = take ? i : ks;
+				UNROLL for (int c = 0; c < 6; c++) tk[c] = take ? t[c] : tk[c];
+			}
+			solve_lower_t<6>(LA, dA, tk);  // A^-1 y_k
+			real w[N];
+			const real wn = rsqrt(best);
+			UNROLL for (int i = 0; i < N; i++) {
+				real s = (ks == i) ? 1.0 : 0.0;
+				UNROLL for (int c = 0; c < 6; c++) s = fma(-Y[i * 6 + c], tk[c], s);
+				w[i] = s * wn;
+			}
+			{  // one re-orthogonalisation pass: w <- w - Y A^-1 Y^T w, renormalise
+				real cw[6];
+				UNROLL for (int c = 0; c < 6; c++) {
+					real s = 0;
+					UNROLL for (int i = 0; i < N; i++) s = fma(Y[i * 6 + c], w[i], s);
+					cw[c] = s;
+				}
+				solve_lower<6>(LA, dA, cw);
+				solve_lower_t<6>(LA, dA, cw);
+				real nn = 0;
+				UNROLL for (int i = 0; i < N; i++) {
+					real s = w[i];
+					UNROLL for (int c = 0; c < 6; c++) s = fma(-Y[i * 6 + c], cw[c], s);
+					w[i] = s;
+					nn = fma(s, s, nn);
+				}
+				const real rn = rsqrt(nn);
+				UNROLL for (int i = 0; i < N; i++) w[i] *= rn;
+			}
+			UNROLL for (int i = 0; i < N; i++) a[i] = w[i];
+			solve_lower_t<N>(L, dL, a);	 // a = L^-T w
+			UNROLL for (int i = 0; i < N; i++) {
+				real s = 0;
+				UNROLL for (int k = 0; k <= i; k++) s = fma(L[i * N + k], w[k], s);
+				bb[i] = s;	// b = L w
+			}
+			UNROLL for (int i = 0; i < N; i++) na2 = fma(a[i], a[i], na2);
+		}
+	}
+	SAI2B_PHASE();
+	// ---- MotionForceTask torques J^T (Lambda_mod F_unit + F_force) = L (Y z)   (SingularityHandler.cpp:307-309)
 	UNROLL for (int i = 0; i < 6; i++) z[i] += Ff[i];
-	real tau_mft[N];
-	mv_t<6, N>(J, z, tau_mft);	// SingularityHandler.cpp:307-309
+	real yz[N], tau_mft[N];
+	mv<N, 6>(Y, z, yz);
+	UNROLL for (int i = 0; i < N; i++) {
+		real s = 0;
+		UNROLL for (int k = 0; k <= i; k++) s = fma(L[i * N + k], yz[k], s);
+		tau_mft[i] = s;
+	}
 	UNROLL for (int i = 0; i < N; i++) tau[i] = tau_mft[i];
 	if (!HAS_JT) return;
 
-	// ---- nullspace of the MotionForceTask as a rank-one projector a b^T
+	// ---- JointTask: the law was evaluated up front (fast_jt_early); project it
 	const DevTask& t1 = P.task[1];
-	real Z[N * 6];	// Y LA^-T: orthonormal columns spanning range(Y)
-	UNROLL for (int i = 0; i < N; i++) {
-		UNROLL for (int c = 0; c < 6; c++) {
-			real s = Y[i * 6 + c];
-			UNROLL for (int k = 0; k < c; k++) s = fma(-Z[i * 6 + k], LA[c * 6 + k], s);
-			Z[i * 6 + c] = s * dA[c];
-		}
-	}
-	real pd[N];	 // diagonal of the complementary projector I - Z Z^T
-	int ks = 0;
-	real best = -1;
-	UNROLL for (int i = 0; i < N; i++) {
-		real s = 1.0;
-		UNROLL for (int c = 0; c < 6; c++) s = fma(-Z[i * 6 + c], Z[i * 6 + c], s);
-		pd[i] = s;
-		if (s > best) {
-			best = s;
-			ks = i;
-		}
-	}
-	real zk[6];
-	UNROLL for (int c = 0; c < 6; c++) {
-		real s = 0;
-		UNROLL for (int i = 0; i < N; i++) s = (ks == i) ? Z[i * 6 + c] : s;
-		zk[c] = s;
-	}
-	real w[N];
-	const real wn = rsqrt(best);
-	UNROLL for (int i = 0; i < N; i++) {
-		real s = (ks == i) ? 1.0 : 0.0;
-		UNROLL for (int c = 0; c < 6; c++) s = fma(-Z[i * 6 + c], zk[c], s);
-		w[i] = s * wn;
-	}
-	// one Gram-Schmidt clean-up pass against range(Z) keeps w orthogonal to 1e-16
-	{
-		real pz[6];
-		UNROLL for (int c = 0; c < 6; c++) {
-			real s = 0;
-			UNROLL for (int i = 0; i < N; i++) s = fma(Z[i * 6 + c], w[i], s);
-			pz[c] = s;
-		}
-		real nn = 0;
-		UNROLL for (int i = 0; i < N; i++) {
-			real s = w[i];
-			UNROLL for (int c = 0; c < 6; c++) s = fma(-Z[i * 6 + c], pz[c], s);
-			w[i] = s;
-			nn = fma(s, s, nn);
-		}
-		const real rn = rsqrt(nn);
-		UNROLL for (int i = 0; i < N; i++) w[i] *= rn;
-	}
-	real a[N], bb[N];
-	UNROLL for (int i = 0; i < N; i++) a[i] = w[i];
-	solve_lower_t<N>(L, dL, a);	 // a = L^-T w
-	UNROLL for (int i = 0; i < N; i++) {
-		real s = 0;
-		UNROLL for (int k = 0; k <= i; k++) s = fma(L[i * N + k], w[k], s);
-		bb[i] = s;	// b = L w
-	}
-	real na2 = 0;
-	UNROLL for (int i = 0; i < N; i++) na2 = fma(a[i], a[i], na2);
-
-	// ---- JointTask law (JointTask.cpp:299-345), S = I
-	real* S = t1.state;
-	const real* G = t1.goals;
 	real af = 0, aacc = 0;
 	UNROLL for (int i = 0; i < N; i++) {
-		const real qd = ld(G, i, B, b), dqd = ld(G, N + i, B, b), ddqd = ld(G, 2 * N + i, B, b);
-		const real integ = fma(rc.q[i] - qd, t1.dt, ld(S, i, B, b));
-		st(S, i, B, b, integ);
-		real f;
-		if (t1.use_vsat) {
-			const real kvi = gain_pinv(t1.kv[i]);
-			real dv = -t1.kp[i] * kvi * (rc.q[i] - qd) - t1.ki[i] * kvi * integ;
-			dv = fmin(fmax(dv, -t1.vsat[i]), t1.vsat[i]);
-			f = -t1.kv[i] * (rc.dq[i] - dv);
-		} else {
-			f = -t1.kp[i] * (rc.q[i] - qd) - t1.kv[i] * (rc.dq[i] - dqd) - t1.ki[i] * integ;
-		}
-		af = fma(a[i], f, af);
-		aacc = fma(a[i], ddqd, aacc);
+		af = fma(a[i], jt.f[i], af);
+		aacc = fma(a[i], jt.ddq[i], aacc);
 	}
-	if (with_comp) {  // JointTask.cpp:285-292: - Jp^T R M_partial R^T S M^-1 tau_prec
+	if (with_comp) {  // JointTask.cpp:285-292: - Jp^T R M_partial R^T S M^-1 tau_prec;  M^-1 tau_mft = L^-T (Y z)
 		real u[N];
-		UNROLL for (int i = 0; i < N; i++) u[i] = tau_mft[i];
-		solve_lower<N>(L, dL, u);
+		UNROLL for (int i = 0; i < N; i++) u[i] = yz[i];
 		solve_lower_t<N>(L, dL, u);
 		UNROLL for (int i = 0; i < N; i++) aacc = fma(-a[i], u[i], aacc);
 	}

@@ -442,6 +442,7 @@ static void fill_dev_task(const sai2b_task_config& c, DevTask& d) {
 	d.cl_force = c.closed_loop_force, d.cl_moment = c.closed_loop_moment;
 	d.fdim = c.force_space_dimension, d.mdim = c.moment_space_dimension;
 	d.lin_vsat = c.linear_saturation_velocity, d.ang_vsat = c.angular_saturation_velocity;
+	d.plain_motion = (d.full_projection && d.fdim == 0 && d.mdim == 0 && !d.use_vsat) ? 1 : 0;
 	// MotionForceTask.cpp:892-971 with rotation = identity (world-frame parametrisation)
 	for (int blk = 0; blk < 2; blk++) {
 		const int dim = blk ? c.moment_space_dimension : c.force_space_dimension;

@@ -94,12 +94,24 @@ __global__ __launch_bounds__(64) void tick_fast_kernel(const DevParams* __restri
 	}
 	const DevTask& t0 = P.task[0];
 	const bool clean = ldi(t0.istate, IS_NTYPES, B, b) == 0;
-	real J[6 * N], x[3], R[9], M[N * N], g[N];
+	// Phase order keeps the live set small (only 256 of the 512 registers are VGPRs the VALU can
+	// address; the rest are AGPRs the compiler uses as spill space) and gives every load a phase of
+	// arithmetic to hide behind: JT law inputs -> FK/Jacobian -> MFT law -> CRBA -> certificate.
+	JtEarly jt;
+	if (FAST == 2) fast_jt_early(P.task[1], rc, B, b, jt);
+	MftIn in0;
+	mft_load(t0, B, b, in0);
+	SAI2B_PHASE();
+	real J[6 * N], M[N * N], g[N], Fu[6], Ff[6];
 	{
 		Frames F;
 		fk(P.model, rc.q, F);
+		real x[3], R[9];
 		frame_pose(t0, F, x, R);
 		jacobian(t0, F, x, J);
+		SAI2B_PHASE();
+		mft_law(t0, rc, J, x, R, in0, Fu, Ff);	// MotionForceTask.cpp:278-503 (integrators not yet stored)
+		SAI2B_PHASE();
 		mass_matrix(P.model, F, M);
 		if (P.gravity_comp)
 			gravity_vector(P.model, F, g);
@@ -107,12 +119,19 @@ __global__ __launch_bounds__(64) void tick_fast_kernel(const DevParams* __restri
 			UNROLL for (int i = 0; i < N; i++) g[i] = 0;
 		}
 	}
+	SAI2B_PHASE();
 	const bool ok = certify_nonsingular(J, t0.s_abs_tol, t0.s_max);
 	const bool all_ok = __all(ok && clean);
 	if (threadIdx.x == 0) ((gint*)wave_flags)[blockIdx.x] = all_ok ? 0 : 1;
 	if (!all_ok) return;
+	// committed to the fast path: integrators can go out now
+	mft_store_integrators(t0, B, b, in0);
+	if (FAST == 2) {
+		UNROLL for (int i = 0; i < N; i++) st(P.task[1].state, i, B, b, jt.integ[i]);
+	}
+	SAI2B_PHASE();
 	real tau[N];
-	fast_tick<FAST == 2>(P, rc, J, x, R, M, B, b, with_comp != 0, tau);
+	fast_tick<FAST == 2>(P, J, M, Fu, Ff, B, b, with_comp != 0, jt, tau);
 	UNROLL for (int i = 0; i < N; i++) st(P.tau, i, B, b, tau[i] + g[i]);
 }
 

@@ -36,6 +36,7 @@ struct DevTask {
 	int link;
 	double frame_pos[3], frame_rot[9];
 	int full_projection; // P == I
+	int plain_motion;	 // full task, world frame, no force/moment space, no velocity saturation
 	double P[36];
 	int rank; // pos_range + ori_range
 	int in_frame;
