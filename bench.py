@@ -30,6 +30,22 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (FETCH_SIZE
+    and WRITE_SIZE are collected in separate passes and reported in KB; FETCH_SIZE under-reads coalesced
+    streams by 2x on gfx950: MI355X_MICROARCH.md §HBM). None when no summary is committed."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_*_counters.json")))
+    if not files:
+        return None
+    data = json.load(open(files[-1]))
+    for name, c in data.items():
+        if "tick_fast_kernel<2>" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            return (2 * c["FETCH_SIZE"]["avg_per_dispatch"] + c["WRITE_SIZE"]["avg_per_dispatch"]) * 1024
+    return None
+
+
 def cpu_baseline(inp, seconds=8.0):
     """the CPU oracle (our FP64 restatement of the reference, -O2) timed on this host's cores on a
     bounded sample of the same workload"""
@@ -116,11 +132,13 @@ def main():
     ctrl.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the ctx stream
+    step_ms_events = ev0.elapsed_time(ev1) / args.steps  # HIP events on the ctx stream, whole step
+    # per-kernel durations, HIP events around each launch on the ctx stream (outside the timed region)
+    kernel_ms, fallback_ms = ctrl.profile_tick(min(args.steps, 100))
     if distributed:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, step_ms_events, kernel_ms, fallback_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
+        elapsed, step_ms_events, kernel_ms, fallback_ms = (float(x) for x in t)
         dist.barrier()
 
     if rank == 0:
@@ -154,12 +172,16 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "kernel": "sai2b::tick_kernel<false>",
+                "traffic": pmc_traffic_bytes(),
+                "kernel": "sai2b::tick_fast_kernel<2>" if args.config in (3, 5) else "first kernel of the tick",
                 "kernel_ms": kernel_ms,
+                "fallback_kernel_ms": fallback_ms,
+                "step_ms_hip_events": step_ms_events,
                 "fp64_vector_frac": (FLOP_PER_TICK * B / (kernel_ms * 1e-3)) / (FP64_VECTOR_PEAK_TFLOPS * 1e12),
-                "note": "algorithmic bytes = 528 B/tick x robots per launch; the path is FP64-VALU/latency bound "
-                        "(SURVEY.md §8(d)), so the FP64 fraction is reported beside the HBM fraction",
+                "note": "achieved = 528 B/tick (SURVEY.md §8(d)) x robots per launch / HIP-event duration of the "
+                        "dominant kernel; the path is FP64-VALU/latency bound, so the FP64 fraction (11.4 kflop/tick "
+                        "formula-level figure) is reported beside the HBM fraction. traffic = 2*FETCH_SIZE + WRITE_SIZE "
+                        "of the committed rocprofv3 --pmc passes of this command (profiles/), per launch",
             },
         }
         if not args.no_cpu_baseline and world == 1:

@@ -238,6 +238,11 @@ int sai2b_get_mft_singularity(sai2b_ctx* ctx, int task, double* sigma, double* a
 /* Sai2Model::M(): [49][B]; J of MFT `task` (JWorldFrame): [42][B]; position [3][B], rotation [9][B] */
 int sai2b_get_model(sai2b_ctx* ctx, int task, double* M, double* J, double* pos, double* rot);
 
+/* Bench bookkeeping: run `steps` fused ticks with HIP events around each kernel launch of the tick (on
+ * the ctx stream) and return the average duration per launch in ms: the first kernel of the tick and,
+ * when the hierarchy takes the SVD-free path, the flag-gated generic kernel behind it (else 0). */
+int sai2b_profile_tick(sai2b_ctx* ctx, int steps, double* first_kernel_ms, double* second_kernel_ms);
+
 /* number of kernel launches and robots processed since creation (bench bookkeeping) */
 int sai2b_counters(const sai2b_ctx* ctx, long long* launches, long long* ticks);
 

@@ -135,7 +135,7 @@ def struct_to_dict(s):
 
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "csrc", "libsai2b.so")
+LIB_PATH = os.environ.get("SAI2B_LIB") or os.path.join(PKG_DIR, "csrc", "libsai2b.so")
 
 # every symbol include/sai2b.h declares (tests check that the built library exports all of them)
 EXPORTS = [
@@ -169,6 +169,7 @@ EXPORTS = [
     "sai2b_get_task_torques",
     "sai2b_get_mft_singularity",
     "sai2b_get_model",
+    "sai2b_profile_tick",
     "sai2b_counters",
 ]
 
@@ -231,6 +232,7 @@ def load_library():
     lib.sai2b_get_task_torques.argtypes = [vp, _i, vp]
     lib.sai2b_get_mft_singularity.argtypes = [vp, _i, vp, vp, vp]
     lib.sai2b_get_model.argtypes = [vp, _i, vp, vp, vp, vp]
+    lib.sai2b_profile_tick.argtypes = [vp, _i, P(_d), P(_d)]
     lib.sai2b_counters.argtypes = [vp, P(C.c_longlong), P(C.c_longlong)]
     _lib = lib
     return lib

@@ -209,6 +209,13 @@ class Controller:
     def device_buffer(self, which, task=-1):
         return self.lib.sai2b_device_buffer(self.h, which, task)
 
+    def profile_tick(self, steps):
+        """-> (first_kernel_ms, second_kernel_ms): HIP-event average duration per launch of each kernel of
+        the fused tick, measured on the ctx stream"""
+        a, b = C.c_double(), C.c_double()
+        self._rc(self.lib.sai2b_profile_tick(self.h, int(steps), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def counters(self):
         a, b = C.c_longlong(), C.c_longlong()
         self.lib.sai2b_counters(self.h, C.byref(a), C.byref(b))

@@ -89,8 +89,6 @@ DI bool certify_nonsingular(const real* J, real s_abs_tol, real s_max) {
 	return ok;
 }
 
-// The fast tick body. J/x/R/M are the model quantities at rc.q; HAS_JT selects the 2-level form.
-// Ordered to keep few matrices alive at once: law -> nullspace vectors (a, b) -> MFT torques -> JT.
 // Inputs of the second-level JointTask law after the early part (fast_jt_early): the PD(+I) unit
 // torques f, the goal accelerations, and the advanced integrators (stored once the wavefront is
 // committed to the fast path).
@@ -115,8 +113,13 @@ DI void fast_jt_early(const DevTask& t1, const RobotCtx& rc, int B, int b, JtEar
 	}
 }
 
+// Scheduling fence between phases (and a marker in the ISA for per-phase inspection): the kernel is
+// one huge basic block, and without fences the scheduler interleaves phases and inflates the live set.
 #define SAI2B_PHASE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("; SAI2B_PHASE_MARK"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
+// The Cholesky part of the fast tick. J and M are the Jacobian and mass matrix at rc.q, Fu/Ff the task
+// forces of the MotionForceTask law, jt the JointTask law; HAS_JT selects the 2-level form. Ordered to
+// keep few matrices alive at once: bounded-inertia side -> Y = L^-1 J^T -> nullspace vectors -> torques.
 template <bool HAS_JT>
 DI void fast_tick(const DevParams& P, const real* J, const real* M, const real* Fu, const real* Ff, int B, int b,
 				  bool with_comp, const JtEarly& jt, real* tau) {

@@ -694,19 +694,20 @@ extern "C" int sai2b_reinitialize(sai2b_ctx* ctx) {
 	return SAI2B_OK;
 }
 
+// eligibility of the SVD-free path (sai2b_fast.hpp): [full MFT] or [full MFT, full JT]; whole wavefronts only
+static int fast_kind(const sai2b_ctx* ctx) {
+	if (ctx->no_fast_path || ctx->T > 2 || ctx->B % 64 != 0 || ctx->cfg[0].type != SAI2B_MOTION_FORCE_TASK ||
+		!ctx->h_params.task[0].full_projection || ctx->h_params.task[0].rank != 6)
+		return 0;
+	if (ctx->T == 1) return 1;
+	return (ctx->cfg[1].type == SAI2B_JOINT_TASK && ctx->h_params.task[1].full_selection) ? 2 : 0;
+}
+
 static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torque) {
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	int rc = upload_params(ctx);
 	if (rc) return rc;
-	// eligibility of the SVD-free path (sai2b_fast.hpp): [full MFT] or [full MFT, full JT], handling enforced
-	int fast = 0;
-	if (!ctx->no_fast_path && ctx->T <= 2 && ctx->cfg[0].type == SAI2B_MOTION_FORCE_TASK && ctx->h_params.task[0].full_projection &&
-		ctx->h_params.task[0].rank == 6) {
-		if (ctx->T == 1)
-			fast = 1;
-		else if (ctx->cfg[1].type == SAI2B_JOINT_TASK && ctx->h_params.task[1].full_selection)
-			fast = 2;
-	}
+	const int fast = fast_kind(ctx);
 	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, commit_sh, with_comp, do_torque, ctx->wave_flags, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
 	ctx->launches++;
@@ -835,6 +836,45 @@ extern "C" int sai2b_get_model(sai2b_ctx* ctx, int task, double* M, double* J, d
 	if ((rc = fetch_dbg(ctx, J, d.dbg_J, 6 * N))) return rc;
 	if ((rc = fetch_dbg(ctx, pos, d.dbg_pose, 3))) return rc;
 	return fetch_dbg(ctx, rot, d.dbg_pose ? d.dbg_pose + 3 * B : nullptr, 9);
+}
+
+// Bench bookkeeping: run `steps` fused ticks with HIP events around EACH kernel launch of the tick on
+// the ctx stream and return the average duration per launch in milliseconds: first kernel of the tick
+// (the SVD-free kernel when the hierarchy is eligible, else the generic kernel) and, when there is
+// one, the flag-gated generic kernel behind it (0 otherwise).
+extern "C" int sai2b_profile_tick(sai2b_ctx* ctx, int steps, double* first_ms, double* second_ms) {
+	if (!ctx || steps < 1) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_profile_tick: bad arguments");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	int rc = upload_params(ctx);
+	if (rc) return rc;
+	const int fast = fast_kind(ctx);
+	const bool two = fast != 0 && !ctx->introspection;
+	std::vector<hipEvent_t> ev(3 * (size_t)steps);
+	for (auto& e : ev) HIP_TRY(ctx, hipEventCreate(&e));
+	for (int s = 0; s < steps; s++) {
+		HIP_TRY(ctx, hipEventRecord(ev[3 * s], ctx->stream));
+		if (sai2b_launch_tick_part(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, 0, ctx->wave_flags, ctx->stream))
+			return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
+		HIP_TRY(ctx, hipEventRecord(ev[3 * s + 1], ctx->stream));
+		if (two && sai2b_launch_tick_part(ctx->d_params, ctx->B, 0, fast, 1, ctx->wave_flags, ctx->stream))
+			return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
+		HIP_TRY(ctx, hipEventRecord(ev[3 * s + 2], ctx->stream));
+	}
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	double a = 0, b = 0;
+	for (int s = 0; s < steps; s++) {
+		float ms = 0;
+		HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[3 * s], ev[3 * s + 1]));
+		a += ms;
+		HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[3 * s + 1], ev[3 * s + 2]));
+		b += ms;
+	}
+	for (auto& e : ev) (void)hipEventDestroy(e);
+	ctx->launches += (two ? 2 : 1) * (long long)steps;
+	ctx->ticks += (long long)steps * ctx->B;
+	if (first_ms) *first_ms = a / steps;
+	if (second_ms) *second_ms = two ? b / steps : 0.0;
+	return SAI2B_OK;
 }
 
 extern "C" int sai2b_counters(const sai2b_ctx* ctx, long long* launches, long long* ticks) {

@@ -198,6 +198,22 @@ extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int de
 	return (int)hipGetLastError();
 }
 
+extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, int debug, int fast, int part, int* wave_flags,
+									  hipStream_t stream) {
+	const dim3 grid((B + 63) / 64), block(64);
+	if (debug)
+		hipLaunchKernelGGL((sai2b::tick_kernel<true>), grid, block, 0, stream, d_params, 1, 1, 1, nullptr);
+	else if (fast == 0)
+		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, 1, 1, 1, nullptr);
+	else if (part == 1)
+		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, 1, 1, 1, wave_flags);
+	else if (fast == 2)
+		hipLaunchKernelGGL((sai2b::tick_fast_kernel<2>), grid, block, 0, stream, d_params, 1, wave_flags);
+	else
+		hipLaunchKernelGGL((sai2b::tick_fast_kernel<1>), grid, block, 0, stream, d_params, 1, wave_flags);
+	return (int)hipGetLastError();
+}
+
 extern "C" int sai2b_launch_reinit(const sai2b::DevParams* d_params, int B, hipStream_t stream) {
 	const int blocks = (B + 63) / 64;
 	hipLaunchKernelGGL(sai2b::reinit_kernel, dim3(blocks), dim3(64), 0, stream, d_params);
