@@ -24,7 +24,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-BYTES_PER_TICK = 528  # q 7 + dq 7 + MFT goals 24 + JT goals 21 + tau 7 doubles
+BYTES_PER_TICK = {2: 360, 3: 528, 4: 576, 5: 528}  # inputs + outputs per tick, doubles x 8
 FLOP_PER_TICK = 11.4e3  # SURVEY.md §8(d), SVD iterations excluded
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6
@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=65536, help="robots per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="robots per GPU (default: the config's size; 65536 for C3)")
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -105,7 +105,7 @@ def main():
 
     import sai2_primitives_perso_amd as pkg
 
-    B = args.batch
+    B = args.batch or (65536 if args.config in (3, 5) else pkg.workloads.CONFIG_BATCH[args.config])
     inp = pkg.workloads.make_inputs(args.config if args.config != 5 else 3, B=B, rank=rank)
     ctrl = pkg.Controller(pkg.panda_model(), pkg.task_configs(inp["tasks"]), B, device=local_rank)
     import oracle_lib as ol  # only for load_inputs (a plain setter loop) and the cpu_baseline leg
@@ -144,7 +144,7 @@ def main():
     if rank == 0:
         total_ticks = B * world * args.steps
         value = total_ticks / elapsed
-        per_launch_bytes = BYTES_PER_TICK * B
+        per_launch_bytes = BYTES_PER_TICK[args.config] * B
         achieved = per_launch_bytes / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "control-ticks/sec (node), 65k batched 7-DOF Panda, 2-task hierarchy",
@@ -160,8 +160,12 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"C{args.config}: {B} batched Panda per GPU, MotionForceTask(6) + nullspace JointTask, "
-                            "library defaults, OTG off (SURVEY.md §8(d))" if args.config in (3, 5) else f"C{args.config}",
+                "workload": {2: f"C2: {B} batched Panda, one 6-DOF MotionForceTask",
+                             3: f"C3: {B} batched Panda per GPU, MotionForceTask(6) + nullspace JointTask",
+                             4: f"C4: {B} batched Panda, partial MotionForceTask(3) + partial JointTask(2) + full JointTask, "
+                                "singularity handling on (generic Jacobi-SVD kernel)",
+                             5: f"C5: {B} batched Panda per GPU (C3 workload sharded)"}[args.config]
+                            + ", library defaults, OTG off (SURVEY.md §8(d))",
                 "robots_per_gpu": B,
                 "global_batch": B * world,
                 "parallelism": f"batch-sharded x{world}, no collective",
@@ -172,13 +176,14 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_bytes(),
-                "kernel": "sai2b::tick_fast_kernel<2>" if args.config in (3, 5) else "first kernel of the tick",
+                "traffic": pmc_traffic_bytes() if args.config in (3, 5) and B == 65536 else None,
+                "kernel": {2: "sai2b::tick_fast_kernel<1>", 3: "sai2b::tick_fast_kernel<2>", 4: "sai2b::tick_kernel<false>",
+                           5: "sai2b::tick_fast_kernel<2>"}[args.config],
                 "kernel_ms": kernel_ms,
                 "fallback_kernel_ms": fallback_ms,
                 "step_ms_hip_events": step_ms_events,
                 "fp64_vector_frac": (FLOP_PER_TICK * B / (kernel_ms * 1e-3)) / (FP64_VECTOR_PEAK_TFLOPS * 1e12),
-                "note": "achieved = 528 B/tick (SURVEY.md §8(d)) x robots per launch / HIP-event duration of the "
+                "note": "achieved = algorithmic bytes/tick (SURVEY.md §8(d): 360/528/576 B for C2/C3/C4) x robots per launch / HIP-event duration of the "
                         "dominant kernel; the path is FP64-VALU/latency bound, so the FP64 fraction (11.4 kflop/tick "
                         "formula-level figure) is reported beside the HBM fraction. traffic = 2*FETCH_SIZE + WRITE_SIZE "
                         "of the committed rocprofv3 --pmc passes of this command (profiles/), per launch",
