@@ -188,6 +188,16 @@ void oracle_svd(int m, int n, const double* A, double* U, double* s, double* V) 
 			for (int r = 0; r < m; r++) U[r * p + k] = X[r * cols + j] * inv;
 			for (int r = 0; r < n; r++) V[r * p + k] = W[r * cols + j];
 		}
+		/* sign convention (DEFINED here; Eigen's is unknown): the right singular vector is oriented so
+		 * that its largest-magnitude component is positive. Only the FK-perturbation classification
+		 * (SingularityHandler.cpp:253-273) depends on the sign. */
+		int big = 0;
+		for (int r = 1; r < n; r++)
+			if (fabs(V[r * p + k]) > fabs(V[big * p + k])) big = r;
+		if (V[big * p + k] < 0) {
+			for (int r = 0; r < n; r++) V[r * p + k] = -V[r * p + k];
+			for (int r = 0; r < m; r++) U[r * p + k] = -U[r * p + k];
+		}
 	}
 }
 

@@ -743,7 +743,19 @@ DI void mft_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B
 					UNROLL for (int i = 0; i < 6; i++) u[i] = W[i * 6 + j];
 					UNROLL for (int i = 0; i < N; i++) v[i] = Q[i * 6 + j];
 				}
-			const real inv = s > 0 ? 1.0 / s : 0.0;
+			real inv = s > 0 ? 1.0 / s : 0.0;
+			{  // sign convention shared with the oracle: largest-magnitude component of v positive
+				real big = 0, bigabs = -1;
+				UNROLL for (int i = 0; i < N; i++) {
+					const bool take = fabs(v[i]) > bigabs;
+					bigabs = take ? fabs(v[i]) : bigabs;
+					big = take ? v[i] : big;
+				}
+				if (big < 0) {
+					inv = -inv;
+					UNROLL for (int i = 0; i < 6; i++) u[i] = -u[i];
+				}
+			}
 			UNROLL for (int i = 0; i < N; i++) v[i] *= inv;
 			if (p == split) {
 				UNROLL for (int i = 0; i < 6; i++) us0[i] = u[i];

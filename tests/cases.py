@@ -22,6 +22,8 @@ def load_case(name):
     config, B, opts, kw = case_table()[name]
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
     inp = pkg.workloads.make_inputs(config, B=B)
+    if kw.get("prepare") == "singular":
+        inp = make_golden.make_singular(inp)
     # the fixture carries its own inputs: check the regenerated workload is the committed one
     assert np.array_equal(inp["q"], z["q"]) and np.array_equal(inp["dq"], z["dq"]), "workload drifted from fixture"
     for t, (kind, _) in enumerate(inp["tasks"]):

@@ -330,7 +330,16 @@ class MotionForceTaskNP:
         self.J = self.P @ Jw
         self.Jp = self.J @ N_prec
         U, s, Vt = np.linalg.svd(self.Jp, full_matrices=False)
-        V = Vt.T
+        V = Vt.T.copy()
+        U = U.copy()
+        # sign convention (DEFINED here, Eigen's is unknown): each right singular vector is oriented so
+        # that its largest-magnitude component is positive; only the FK-perturbation classification
+        # (SingularityHandler.cpp:253-273) depends on it
+        for j in range(V.shape[1]):
+            k = np.argmax(np.abs(V[:, j]))
+            if V[k, j] < 0:
+                V[:, j] *= -1
+                U[:, j] *= -1
         self.sv = s
         r = self.rank
         if s[0] < self.s_abs:
@@ -534,6 +543,18 @@ class MotionForceTaskNP:
         return self.N @ self.N_prec
 
 
+def make_singular(inp):
+    """park the first half of the robots near the elbow singularity and the second half near the wrist
+    singularity (inside the blending region s_i/s_0 < 6e-2 of the SingularityHandler)"""
+    B = inp["B"]
+    rng = np.random.default_rng(99)
+    q = inp["q"].copy()
+    q[3, : B // 2] = rng.uniform(-0.11, -0.0705, size=B // 2)
+    q[5, B // 2 :] = rng.uniform(0.0, 0.05, size=B - B // 2)
+    inp["q"] = q
+    return inp
+
+
 def run_case(inp, task_opts=None, gravity_comp=False, with_comp=True, extra=None, ticks=1):
     """Run the numpy restatement over all robots of a workloads.make_inputs() dict.
     extra(b, tasks) may install per-robot goal wrenches / sensed wrenches. Returns a dict of SoA
@@ -671,6 +692,11 @@ def cases():
                                            "closed_loop_force": True, "closed_loop_moment": True,
                                            "in_compliant_frame": True}, {}],
          {"extra": install_wrench, "wrench": wrench, "ticks": 2}),
+        # 6-DOF task inside the singularity-blending region for several ticks: SVD split, type-1/type-2
+        # classification, 200-deep history counters, blended torques (SingularityHandler.cpp:100-368)
+        ("c3_singular_4ticks", 3, 96, None, {"ticks": 4, "prepare": "singular"}),
+        ("c3_singular_type1_enforced", 3, 48, [{"enforce_type_1": True}, {}], {"ticks": 2, "prepare": "singular"}),
+        ("c3_singular_no_handling", 3, 48, [{"enforce_handling": False}, {}], {"prepare": "singular"}),
     ]
 
 
@@ -679,6 +705,8 @@ def main():
         inp = workloads.make_inputs(config, B=B)
         kw = dict(kw)
         wrench = kw.pop("wrench", None)
+        if kw.pop("prepare", None) == "singular":
+            inp = make_singular(inp)
         out = run_case(inp, task_opts=opts, **kw)
         data = flatten_inputs(inp)
         if wrench:
