@@ -585,12 +585,65 @@ DI void sandwich7(const real* Jp, const real* A, real* out) {
 	mm_nt_sym<N, N>(T, Jp, out);
 }
 
+// ------------------------------------------------------------------ SVD-free certificates
+// Certificate that a symmetric PSD Gram matrix G (n x n) restricted to the range it lives in has
+// lambda_max >= abs2 and lambda_min >= rel2 * lambda_max, i.e. for G = Jp Jp^T that s_0 >= sqrt(abs2)
+// and s_min / s_0 >= sqrt(rel2): lambda_max(G) <= ub := tr(G^8)^(1/8) <= n^(1/8) lambda_max(G), and
+// positive LDL^T pivots of G + ub Pc - rel2 ub I (Pc = projector onto the complement of the range, or
+// NULL when the range is everything) imply the bound. Sufficient, never necessary: whoever fails it
+// takes the Jacobi-SVD path, so decisions are the reference's in all cases.
+template <int n>
+DI bool certify_gram(const real* G, const real* Pc, real abs2, real rel2) {
+	real G2[n * n], G4[n * n];
+	mm_nt_sym<n, n>(G, G, G2);	// G symmetric: G G^T = G^2
+	mm_nt_sym<n, n>(G2, G2, G4);
+	real t8 = 0;
+	UNROLL for (int i = 0; i < n; i++) UNROLL for (int j = 0; j <= i; j++) {
+		real v = G4[i * n + j] * G4[i * n + j];
+		t8 += (i == j) ? v : 2 * v;
+	}
+	const real ub = sqrt(sqrt(sqrt(t8)));
+	bool ok = ub > 1.28 * abs2;	 // lambda_max >= ub / n^(1/8), 7^(1/8) = 1.2754
+	const real c = rel2 * ub * (1.0 + 1e-9);
+	const real floor_ = 1e-5 * c;
+	real Lm[n * n], d[n];
+	UNROLL for (int j = 0; j < n; j++) {
+		real s = G[j * n + j] - c + (Pc ? ub * Pc[j * n + j] : 0.0);
+		UNROLL for (int k = 0; k < j; k++) s = fma(-Lm[j * n + k] * Lm[j * n + k], d[k], s);
+		d[j] = s;
+		ok = ok && (s > floor_);
+		const real inv = 1.0 / s;
+		UNROLL for (int i = j + 1; i < n; i++) {
+			real t = G[i * n + j] + (Pc ? ub * Pc[i * n + j] : 0.0);
+			UNROLL for (int k = 0; k < j; k++) t = fma(-Lm[i * n + k] * Lm[j * n + k], d[k], t);
+			Lm[i * n + j] = t * inv;
+		}
+	}
+	return ok;
+}
+
+// Row space accumulated over the certified tasks of the hierarchy: W stacks the (full-row-rank)
+// projected Jacobians, so range(N_prec) = null(W) and a full JointTask that follows gets its range
+// projector as I - W^T (W W^T)^-1 W instead of an SVD of N_prec (JointTask.cpp:233).
+struct Chain {
+	bool ok;	// every task so far was certified by the whole wavefront
+	int wrows;	// batch-uniform
+	real W[N * N];
+};
+DI void chain_append(Chain& ch, const real* rows, int nrows) {
+	UNROLL for (int R = 0; R < N; R++) UNROLL for (int i = 0; i < N; i++) {
+		const bool hit = (i < nrows) && (R == ch.wrows + i);
+		UNROLL for (int j = 0; j < N; j++) ch.W[R * N + j] = hit ? rows[i * N + j] : ch.W[R * N + j];
+	}
+	ch.wrows += nrows;
+}
+
 // MotionForceTask::updateTaskModel + SingularityHandler::updateTaskModel/classifySingularity +
 // MotionForceTask::computeTorques + SingularityHandler::computeTorques for one robot
 // (MotionForceTask.cpp:247-509, SingularityHandler.cpp:75-368).
 template <bool DEBUG>
 DI void mft_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B, int b, bool first, bool last,
-				 bool commit_sh, bool do_torque, real* Nprec, real* tau_total) {
+				 bool commit_sh, bool do_torque, real* Nprec, real* tau_total, Chain& chain) {
 	Frames F;
 	fk(P.model, rc.q, F);
 	real x[3], R[9], Jw[6 * N], J[6 * N], Jp[6 * N];
@@ -606,60 +659,85 @@ DI void mft_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B
 	} else {
 		mm<6, N, N>(J, Nprec, Jp);
 	}
-	// ---- thin SVD of Jp via one-sided Jacobi on Jp^T (7x6): Jp^T W = Q, U = W, V = Q / s
-	real Q[N * 6], W[36];
-	UNROLL for (int i = 0; i < 6; i++) UNROLL for (int j = 0; j < N; j++) Q[j * 6 + i] = Jp[i * N + j];
-	hestenes<N, 6>(Q, W);
-	real sv[6];
-	UNROLL for (int j = 0; j < 6; j++) {
-		real a = 0;
-		UNROLL for (int r = 0; r < N; r++) a = fma(Q[r * 6 + j], Q[r * 6 + j], a);
-		sv[j] = sqrt(a);
-	}
-	int pos[6];	 // rank of column j in descending singular-value order
-	real ss[6];	 // sorted singular values
-	UNROLL for (int j = 0; j < 6; j++) {
-		int p = 0;
-		UNROLL for (int k = 0; k < 6; k++) p += (sv[k] > sv[j] || (sv[k] == sv[j] && k < j)) ? 1 : 0;
-		pos[j] = p;
-	}
-	UNROLL for (int p = 0; p < 6; p++) {
-		real s = 0;
-		UNROLL for (int j = 0; j < 6; j++) s = (pos[j] == p) ? sv[j] : s;
-		ss[p] = s;
-	}
-	// ---- range split (SingularityHandler.cpp:83-143)
+	// ---- branch decision (SingularityHandler.cpp:83-143). First an SVD-free certificate that the whole
+	// wavefront is in the "fully non-singular" branch (then U_ns spans range(P) and only the projector
+	// P is needed); the introspection build always runs the SVD because it reports singular values.
 	const int rank = t.rank;
-	int split;
-	real alpha;
-	if (ss[0] < t.s_abs_tol) {
-		split = 0;
-		alpha = 0;
+	bool certified = false;
+	if (!DEBUG) {
+		real G[36], Pc[36];
+		mm_nt_sym<6, N>(Jp, Jp, G);
+		UNROLL for (int i = 0; i < 6; i++) UNROLL for (int j = 0; j < 6; j++) Pc[i * 6 + j] = ((i == j) ? 1.0 : 0.0) - t.P[i * 6 + j];
+		certified = __all(certify_gram<6>(G, t.full_projection ? nullptr : Pc, t.s_abs_tol * t.s_abs_tol, t.s_max * t.s_max));
+	}
+	real Q[N * 6], W[36], sv[6], ss[6], Pns[36], Ps[36], alpha = 1;
+	int pos[6], split = rank;
+	if (certified) {
+		UNROLL for (int i = 0; i < 36; i++) {
+			Pns[i] = t.P[i];
+			Ps[i] = 0;
+			W[i] = 0;
+		}
+		UNROLL for (int i = 0; i < N * 6; i++) Q[i] = 0;
+		UNROLL for (int i = 0; i < 6; i++) {
+			sv[i] = ss[i] = 0;
+			pos[i] = i;
+		}
+		if (chain.ok) {	 // row space of this task for a later full JointTask
+			real rows[N * N];
+			UNROLL for (int i = 0; i < N * N; i++) rows[i] = 0;
+			mm_tn<6, 6, N>(t.PU, Jp, rows);	 // rows >= rank are zero (PU has `rank` non-zero columns)
+			chain_append(chain, rows, rank);
+		}
 	} else {
-		split = rank;
-		alpha = 1;
-		bool found = false;
-		UNROLL for (int i = 1; i < 6; i++) {
-			real icn = ss[i] / ss[0];
-			if (i < rank && !found && icn < t.s_max) {
-				alpha = fmin(fmax((icn - t.s_min) / (t.s_max - t.s_min), 0.0), 1.0);
-				split = i;
-				found = true;
+		chain.ok = false;
+		// ---- thin SVD of Jp via one-sided Jacobi on Jp^T (7x6): Jp^T W = Q, U = W, V = Q / s
+		UNROLL for (int i = 0; i < 6; i++) UNROLL for (int j = 0; j < N; j++) Q[j * 6 + i] = Jp[i * N + j];
+		hestenes<N, 6>(Q, W);
+		UNROLL for (int j = 0; j < 6; j++) {
+			real a = 0;
+			UNROLL for (int r = 0; r < N; r++) a = fma(Q[r * 6 + j], Q[r * 6 + j], a);
+			sv[j] = sqrt(a);
+		}
+		UNROLL for (int j = 0; j < 6; j++) {
+			int p = 0;
+			UNROLL for (int k = 0; k < 6; k++) p += (sv[k] > sv[j] || (sv[k] == sv[j] && k < j)) ? 1 : 0;
+			pos[j] = p;
+		}
+		UNROLL for (int p = 0; p < 6; p++) {
+			real s = 0;
+			UNROLL for (int j = 0; j < 6; j++) s = (pos[j] == p) ? sv[j] : s;
+			ss[p] = s;
+		}
+		// ---- range split (SingularityHandler.cpp:83-143)
+		if (ss[0] < t.s_abs_tol) {
+			split = 0;
+			alpha = 0;
+		} else {
+			split = rank;
+			alpha = 1;
+			bool found = false;
+			UNROLL for (int i = 1; i < 6; i++) {
+				real icn = ss[i] / ss[0];
+				if (i < rank && !found && icn < t.s_max) {
+					alpha = fmin(fmax((icn - t.s_min) / (t.s_max - t.s_min), 0.0), 1.0);
+					split = i;
+					found = true;
+				}
 			}
+		}
+		UNROLL for (int i = 0; i < 6; i++) UNROLL for (int k = 0; k <= i; k++) {
+			real a = 0, c = 0;
+			UNROLL for (int j = 0; j < 6; j++) {
+				real uu = W[i * 6 + j] * W[k * 6 + j];
+				a += (pos[j] < split) ? uu : 0.0;
+				c += (pos[j] >= split && pos[j] < rank) ? uu : 0.0;
+			}
+			Pns[i * 6 + k] = Pns[k * 6 + i] = a;
+			Ps[i * 6 + k] = Ps[k * 6 + i] = c;
 		}
 	}
 	const int sc = rank - split;
-	real Pns[36], Ps[36];
-	UNROLL for (int i = 0; i < 6; i++) UNROLL for (int k = 0; k <= i; k++) {
-		real a = 0, c = 0;
-		UNROLL for (int j = 0; j < 6; j++) {
-			real uu = W[i * 6 + j] * W[k * 6 + j];
-			a += (pos[j] < split) ? uu : 0.0;
-			c += (pos[j] >= split && pos[j] < rank) ? uu : 0.0;
-		}
-		Pns[i * 6 + k] = Pns[k * 6 + i] = a;
-		Ps[i * 6 + k] = Ps[k * 6 + i] = c;
-	}
 	const bool bie = t.decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES;
 	const bool impedance = t.decoupling == SAI2B_IMPEDANCE;
 	// ---- non-singular part: Lambda_ns (embedded), N_ns (SingularityHandler.cpp:110-114,130-134)
@@ -928,7 +1006,7 @@ DI void mft_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B
 // JointTask::updateTaskModel + computeTorques(tau_prec) for one robot (JointTask.cpp:218-356)
 template <bool DEBUG>
 DI void jt_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B, int b, bool first, bool last,
-				bool with_comp, bool do_torque, real* Nprec, real* tau_total) {
+				bool with_comp, bool do_torque, real* Nprec, real* tau_total, Chain& chain) {
 	real Jp[N * N];
 	if (first) {
 		UNROLL for (int i = 0; i < N * N; i++) Jp[i] = t.S[i];
@@ -940,14 +1018,44 @@ DI void jt_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B,
 	// range projector of Jp (Sai2Model::matrixRangeBasis, tolerance 1e-3: SURVEY App. D)
 	real PR[N * N];
 	bool zero_range = false;
+	bool need_svd = false;
 	if (first) {
-		// Jp = S, orthonormal-rank k0 by construction of the task: R = I_k0
+		// Jp = S, full row rank by construction of the task (JointTask.cpp:34-39): R = I_k0
 		UNROLL for (int i = 0; i < N * N; i++) PR[i] = 0;
 		UNROLL for (int i = 0; i < N; i++) PR[i * N + i] = (i < t.k0) ? 1.0 : 0.0;
-		if (!t.full_selection) {
-			// general S: projector onto range(S) in task coordinates is still I_k0 (full row rank)
+		if (chain.ok) chain_append(chain, Jp, t.k0);
+	} else if (!DEBUG && t.full_selection && chain.ok) {
+		// Jp = N_prec behind certified tasks: range(N_prec) = null(W), no SVD needed
+		zero_range = chain.wrows >= N;
+		real WWt[N * N], X[N * N], T[N * N];
+		mm_nt_sym<N, N>(chain.W, chain.W, WWt);
+		UNROLL for (int i = 0; i < N; i++) WWt[i * N + i] += (i < chain.wrows) ? 0.0 : 1.0;
+		spd_inverse<N>(WWt, X);
+		mm<N, N, N>(X, chain.W, T);
+		UNROLL for (int i = 0; i < N; i++) UNROLL for (int k = 0; k <= i; k++) {
+			real a = (i == k) ? 1.0 : 0.0;
+			UNROLL for (int l = 0; l < N; l++) a = fma(-chain.W[l * N + i], T[l * N + k], a);
+			PR[i * N + k] = PR[k * N + i] = a;
+		}
+		chain.wrows = N;  // a full JointTask closes the hierarchy
+	} else if (!DEBUG && !t.full_selection) {
+		// partial task: certified full row rank (all k0 singular values above the 1e-3 rule) -> R = I_k0
+		real C0[N * N], Pc[N * N];
+		mm_nt_sym<N, N>(Jp, Jp, C0);
+		UNROLL for (int i = 0; i < N * N; i++) Pc[i] = 0;
+		UNROLL for (int i = 0; i < N; i++) Pc[i * N + i] = (i < t.k0) ? 0.0 : 1.0;
+		if (__all(certify_gram<N>(C0, Pc, 1e-6, 1e-6))) {
+			UNROLL for (int i = 0; i < N * N; i++) PR[i] = 0;
+			UNROLL for (int i = 0; i < N; i++) PR[i * N + i] = (i < t.k0) ? 1.0 : 0.0;
+			if (chain.ok) chain_append(chain, Jp, t.k0);
+		} else {
+			need_svd = true;
 		}
 	} else {
+		need_svd = true;
+	}
+	if (need_svd) {
+		chain.ok = false;
 		real X[N * N], W[N * N], sv[N];
 		UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j < N; j++) X[j * N + i] = Jp[i * N + j];
 		hestenes<N, N>(X, W);

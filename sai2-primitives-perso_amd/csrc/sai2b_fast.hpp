@@ -58,35 +58,9 @@ DI void solve_lower_t(const real* L, const real* dinv, real* x) {
 
 // Certificate for "s_0 >= s_abs_tol and s_5 / s_0 >= s_max" on the 6 x 7 Jacobian (see header).
 DI bool certify_nonsingular(const real* J, real s_abs_tol, real s_max) {
-	real G[36], G2[36], G4[36];
+	real G[36];
 	mm_nt_sym<6, N>(J, J, G);
-	mm_nt_sym<6, 6>(G, G, G2);	// G symmetric: G G^T = G^2
-	mm_nt_sym<6, 6>(G2, G2, G4);
-	real t8 = 0;
-	UNROLL for (int i = 0; i < 6; i++) UNROLL for (int j = 0; j <= i; j++) {
-		real v = G4[i * 6 + j] * G4[i * 6 + j];
-		t8 += (i == j) ? v : 2 * v;
-	}
-	const real ub = sqrt(sqrt(sqrt(t8)));  // lambda_max <= ub <= 6^(1/8) lambda_max
-	// s_0^2 = lambda_max >= ub / 6^(1/8)
-	bool ok = ub > 1.2511 * s_abs_tol * s_abs_tol;
-	// LDL^T pivots of G - c I, c slightly above s_max^2 ub
-	const real c = s_max * s_max * ub * (1.0 + 1e-9);
-	const real floor_ = 1e-11 * ub;
-	real Lm[36], d[6];
-	UNROLL for (int j = 0; j < 6; j++) {
-		real s = G[j * 6 + j] - c;
-		UNROLL for (int k = 0; k < j; k++) s = fma(-Lm[j * 6 + k] * Lm[j * 6 + k], d[k], s);
-		d[j] = s;
-		ok = ok && (s > floor_);
-		const real inv = 1.0 / s;
-		UNROLL for (int i = j + 1; i < 6; i++) {
-			real t = G[i * 6 + j];
-			UNROLL for (int k = 0; k < j; k++) t = fma(-Lm[i * 6 + k] * Lm[j * 6 + k], d[k], t);
-			Lm[i * 6 + j] = t * inv;
-		}
-	}
-	return ok;
+	return certify_gram<6>(G, nullptr, s_abs_tol * s_abs_tol, s_max * s_max);
 }
 
 // Inputs of the second-level JointTask law after the early part (fast_jt_early): the PD(+I) unit

@@ -428,6 +428,19 @@ static void fill_dev_task(const sai2b_task_config& c, DevTask& d) {
 		if (c.partial_projection[i] != ((i % 7 == 0) ? 1.0 : 0.0)) pid = false;
 	d.full_projection = pid ? 1 : 0;
 	d.rank = c.pos_range + c.ori_range;
+	{  // basis of range(P): eigenvectors of the projector with eigenvalue 1
+		double w[6], V[36];
+		sym_eig(6, c.partial_projection, w, V);
+		for (int i = 0; i < 36; i++) d.PU[i] = 0;
+		int col = 0;
+		for (int j = 0; j < 6 && col < d.rank; j++)
+			if (w[j] > 0.5) {
+				for (int i = 0; i < 6; i++) d.PU[i * 6 + col] = V[i * 6 + j];
+				col++;
+			}
+		if (pid)
+			for (int i = 0; i < 36; i++) d.PU[i] = (i % 7 == 0) ? 1.0 : 0.0;
+	}
 	d.in_frame = c.parametrization_in_compliant_frame;
 	for (int i = 0; i < 3; i++) {
 		d.kp_pos[i] = c.kp_pos[i], d.kv_pos[i] = c.kv_pos[i], d.ki_pos[i] = c.ki_pos[i];

@@ -62,14 +62,18 @@ __global__ __launch_bounds__(64) void tick_kernel(const DevParams* __restrict__ 
 	real Nprec[N * N], tau[N];
 	UNROLL for (int i = 0; i < N * N; i++) Nprec[i] = (i % (N + 1) == 0) ? 1.0 : 0.0;
 	UNROLL for (int i = 0; i < N; i++) tau[i] = 0;
+	Chain chain;
+	chain.ok = !DEBUG;
+	chain.wrows = 0;
+	UNROLL for (int i = 0; i < N * N; i++) chain.W[i] = 0;
 #pragma unroll 1
 	for (int t = 0; t < P.n_tasks; t++) {
 		const DevTask& tk = P.task[t];
 		const bool first = (t == 0), last = (t == P.n_tasks - 1);
 		if (tk.type == SAI2B_MOTION_FORCE_TASK)
-			mft_task<DEBUG>(P, tk, rc, B, b, first, last, commit_sh != 0, do_torque != 0, Nprec, tau);
+			mft_task<DEBUG>(P, tk, rc, B, b, first, last, commit_sh != 0, do_torque != 0, Nprec, tau, chain);
 		else
-			jt_task<DEBUG>(P, tk, rc, B, b, first, last, with_comp != 0, do_torque != 0, Nprec, tau);
+			jt_task<DEBUG>(P, tk, rc, B, b, first, last, with_comp != 0, do_torque != 0, Nprec, tau, chain);
 	}
 	if (do_torque) {
 		UNROLL for (int i = 0; i < N; i++) st(P.tau, i, B, b, tau[i] + g[i]);  // RobotController.cpp:70-72

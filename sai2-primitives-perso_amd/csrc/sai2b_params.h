@@ -38,6 +38,7 @@ struct DevTask {
 	int full_projection; // P == I
 	int plain_motion;	 // full task, world frame, no force/moment space, no velocity saturation
 	double P[36];
+	double PU[36];	// orthonormal basis of range(P) in its first `rank` columns (row-major 6x6), rest zero
 	int rank; // pos_range + ori_range
 	int in_frame;
 	double kp_pos[3], kv_pos[3], ki_pos[3], kp_ori[3], kv_ori[3], ki_ori[3];

@@ -139,6 +139,83 @@ def test_fast_path_falls_back_per_wavefront():
         assert _err(g.tick(), o.tick()).max() < TOL
 
 
+def _custom_inputs(tasks, B, seed, singular_fraction=0.0):
+    """workload for an arbitrary hierarchy: tasks = [("mft", {"partial": ...}) | ("jt", {"selection": ...})]"""
+    rng = np.random.default_rng(seed)
+    wl = pkg.workloads
+    q = wl.sample_poses(rng, B, singular_fraction=singular_fraction)
+    dq = rng.normal(0, 0.3, size=(B, N))
+    inp = {"B": B, "tasks": tasks, "q": np.ascontiguousarray(q.T), "dq": np.ascontiguousarray(dq.T)}
+    R, p = wl.fk(q)
+    _, x, Rf = wl.frame_jacobian(R, p)
+    for t, (kind, prm) in enumerate(tasks):
+        if kind == "mft":
+            ax = rng.normal(size=(B, 3))
+            ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+            rot = Rf @ wl._expmap(ax * rng.uniform(0, 0.2, size=(B, 1)))
+            inp[f"mft{t}"] = {"pos": np.ascontiguousarray((x + rng.uniform(-0.05, 0.05, size=(B, 3))).T),
+                              "rot": np.ascontiguousarray(rot.reshape(B, 9).T),
+                              "v": np.ascontiguousarray(rng.normal(0, 0.05, size=(B, 3)).T),
+                              "w": np.ascontiguousarray(rng.normal(0, 0.05, size=(B, 3)).T),
+                              "a": np.ascontiguousarray(rng.normal(0, 0.1, size=(B, 3)).T),
+                              "alpha": np.ascontiguousarray(rng.normal(0, 0.1, size=(B, 3)).T)}
+        else:
+            S = np.eye(N) if prm["selection"] is None else prm["selection"]
+            k0 = S.shape[0]
+            inp[f"jt{t}"] = {"q": np.ascontiguousarray(((S @ q.T).T + rng.normal(0, 0.1, size=(B, k0))).T),
+                             "dq": np.ascontiguousarray(rng.normal(0, 0.1, size=(k0, B))),
+                             "ddq": np.ascontiguousarray(rng.normal(0, 0.2, size=(k0, B)))}
+    return inp
+
+
+def _sel(*joints):
+    S = np.zeros((len(joints), N))
+    for r, j in enumerate(joints):
+        S[r, j] = 1
+    return S
+
+
+HIERARCHIES = {
+    "c4": [("mft", {"partial": (np.eye(3), np.zeros((0, 3)))}), ("jt", {"selection": _sel(0, 6)}), ("jt", {"selection": None})],
+    "partial_mft_mixed": [("mft", {"partial": (np.array([[1.0, 0, 0], [0, 1.0, 1.0]]), np.array([[0, 0, 1.0]]))}),
+                          ("jt", {"selection": _sel(1, 3, 5)}), ("jt", {"selection": None})],
+    "jt_first": [("jt", {"selection": _sel(0, 1)}), ("mft", {"partial": (np.eye(3), np.zeros((0, 3)))}),
+                 ("jt", {"selection": None})],
+    "mft_then_overconstrained_jt": [("mft", {"partial": None}), ("jt", {"selection": _sel(2, 4)}), ("jt", {"selection": None})],
+    "four_levels": [("mft", {"partial": (np.array([[0, 0, 1.0]]), np.zeros((0, 3)))}),
+                    ("mft", {"partial": (np.zeros((0, 3)), np.eye(3))}), ("jt", {"selection": _sel(0)}),
+                    ("jt", {"selection": None})],
+    "weighted_selection": [("jt", {"selection": np.array([[1.0, 0.5, 0, 0, 0, 0, 0], [0, 0, 0, 1.0, -1.0, 0, 0]])}),
+                           ("jt", {"selection": None})],
+}
+
+
+@pytest.mark.parametrize("name", list(HIERARCHIES))
+def test_certified_generic_path_matches_oracle(name):
+    """no introspection -> the generic kernel skips the Jacobi SVDs for wavefronts whose robots all
+    carry the non-singularity / full-row-rank certificates (sai2b_device.hpp: certify_gram, Chain);
+    results must equal the oracle's (which always runs the SVDs) and the always-SVD introspection build"""
+    B = 1024
+    inp = _custom_inputs(HIERARCHIES[name], B, seed=hash(name) % 1000, singular_fraction=0.05)
+    o, g = _pair(inp, introspection=False)
+    _, g_svd = _pair(inp, introspection=True)
+    for c in (o, g, g_svd):
+        ol.load_inputs(c, inp)
+    for tick in range(2):
+        tau_o, tau_g, tau_s = o.tick(), g.tick(), g_svd.tick()
+        regular = np.ones(B, dtype=bool)
+        for t, (kind, _) in enumerate(inp["tasks"]):
+            if kind == "mft":
+                _, _, ro = o.get_mft_singularity(t)
+                regular &= ro == (o.tasks[t].pos_range + o.tasks[t].ori_range)
+        assert regular.sum() > B // 2
+        for tau in (tau_g, tau_s):
+            e = _err(tau, tau_o)
+            assert e[regular].max() < TOL, (name, tick, e[regular].max())
+            if (~regular).any():
+                assert e[~regular].max() < 1e-6, (name, tick, e[~regular].max())
+
+
 def test_fused_tick_equals_split_api_and_is_repeatable():
     inp = pkg.workloads.make_inputs(3, B=1024, seed=77)
     g = pkg.Controller(pkg.panda_model(), pkg.task_configs(inp["tasks"]), inp["B"])
