@@ -168,8 +168,8 @@ class Controller:
         self._rc(self.lib.sai2b_set_mft_sensed_wrench(self.h, task, ins[0][0], ins[1][0], self._dev(f, m)))
 
     def set_jt_goals(self, task, q=None, dq=None, ddq=None):
-        if not (0 <= task < len(self.tasks)):
-            raise ValueError("bad task index")
+        if not (0 <= task < len(self.tasks)) or self.tasks[task].type != _abi.JOINT_TASK:
+            raise ValueError("sai2b_set_jt_goals: task is not a JointTask")
         k0 = self.tasks[task].task_dof
         ins = [self._in(o, k0) for o in (q, dq, ddq)]
         self._rc(self.lib.sai2b_set_jt_goals(self.h, task, *[p for p, _ in ins], self._dev(q, dq, ddq)))
