@@ -89,21 +89,21 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="robots per GPU (default: the config's size; 65536 for C3)")
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import sai2_primitives_perso_amd as pkg
+
+    rank, local_rank, world = pkg.sharding.env_rank()
+    if args.single_device:
+        local_rank = 0
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
-    if distributed:
-        import torch.distributed as dist
-
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    import sai2_primitives_perso_amd as pkg
+    pkg.sharding.init(args.backend, local_rank)  # no-op when WORLD_SIZE == 1
+    red_device = "cuda" if args.backend == "nccl" else "cpu"
 
     B = args.batch or (65536 if args.config in (3, 5) else pkg.workloads.CONFIG_BATCH[args.config])
     inp = pkg.workloads.make_inputs(args.config if args.config != 5 else 3, B=B, rank=rank)
@@ -117,8 +117,7 @@ def main():
     def barrier():
         ctrl.synchronize()
         torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
+        pkg.sharding.barrier()
 
     for _ in range(args.warmup):
         ctrl.tick(want_output=False)
@@ -129,21 +128,18 @@ def main():
     for _ in range(args.steps):
         ctrl.tick(want_output=False)
     ev1.record(stream)
-    ctrl.synchronize()
-    torch.cuda.synchronize()
+    barrier()  # ctx stream drained + device synchronize + all ranks arrived
     elapsed = time.perf_counter() - t0
     step_ms_events = ev0.elapsed_time(ev1) / args.steps  # HIP events on the ctx stream, whole step
     # per-kernel durations, HIP events around each launch on the ctx stream (outside the timed region)
     kernel_ms, fallback_ms = ctrl.profile_tick(min(args.steps, 100))
-    if distributed:
-        t = torch.tensor([elapsed, step_ms_events, kernel_ms, fallback_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, step_ms_events, kernel_ms, fallback_ms = (float(x) for x in t)
-        dist.barrier()
+    # the slowest rank defines the job: MAX over ranks (the only communication of the whole run)
+    elapsed, step_ms_events, kernel_ms, fallback_ms = pkg.sharding.max_over_ranks(
+        [elapsed, step_ms_events, kernel_ms, fallback_ms], device=red_device)
+    pkg.sharding.barrier()
 
     if rank == 0:
-        total_ticks = B * world * args.steps
-        value = total_ticks / elapsed
+        value = pkg.sharding.node_throughput(B, world, args.steps, elapsed)
         per_launch_bytes = BYTES_PER_TICK[args.config] * B
         achieved = per_launch_bytes / (kernel_ms * 1e-3) / 1e9
         out = {
@@ -192,8 +188,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(inp)
         print(json.dumps(out), flush=True)
-    if distributed:
-        dist.destroy_process_group()
+    pkg.sharding.finalize()
 
 
 if __name__ == "__main__":
