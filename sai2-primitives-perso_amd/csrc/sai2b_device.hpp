@@ -276,32 +276,16 @@ DI void mass_matrix(const DevModel& md, const Frames& F, real* M) {
 		UNROLL for (int a = 0; a < 3; a++)
 			c[a] = fma(R[3 * a], md.com[k][0], fma(R[3 * a + 1], md.com[k][1], fma(R[3 * a + 2], md.com[k][2], F.p[k][a])));
 		const real* li = md.inertia[k];
+		real Il[9] = {li[0], li[3], li[4], li[3], li[1], li[5], li[4], li[5], li[2]}, T[9];
+		mm<3, 3, 3>(R, Il, T);
 		const real m = md.mass[k];
 		const real c2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
 		const int ia[6] = {0, 1, 2, 0, 0, 1}, ib[6] = {0, 1, 2, 1, 2, 2};
-		// link inertia rotated to the world, by kind (batch-uniform): isotropic tensors do not rotate,
-		// diagonal ones need 27 instead of 45 multiply-adds
-		real Iw[6];
-		if (md.inertia_kind[k] == 2) {
-			UNROLL for (int e = 0; e < 6; e++) Iw[e] = (e < 3) ? li[0] : 0.0;
-		} else if (md.inertia_kind[k] == 1) {
-			real T[9];
-			UNROLL for (int a = 0; a < 3; a++) UNROLL for (int l = 0; l < 3; l++) T[3 * a + l] = R[3 * a + l] * li[l];
-			UNROLL for (int e = 0; e < 6; e++) {
-				real s = 0;
-				UNROLL for (int l = 0; l < 3; l++) s = fma(T[3 * ia[e] + l], R[3 * ib[e] + l], s);
-				Iw[e] = s;
-			}
-		} else {
-			real Il[9] = {li[0], li[3], li[4], li[3], li[1], li[5], li[4], li[5], li[2]}, T[9];
-			mm<3, 3, 3>(R, Il, T);
-			UNROLL for (int e = 0; e < 6; e++) {
-				real s = 0;
-				UNROLL for (int l = 0; l < 3; l++) s = fma(T[3 * ia[e] + l], R[3 * ib[e] + l], s);
-				Iw[e] = s;
-			}
+		UNROLL for (int e = 0; e < 6; e++) {
+			real s = 0;
+			UNROLL for (int l = 0; l < 3; l++) s = fma(T[3 * ia[e] + l], R[3 * ib[e] + l], s);
+			IO[e] += s + m * ((ia[e] == ib[e] ? c2 : 0.0) - c[ia[e]] * c[ib[e]]);
 		}
-		UNROLL for (int e = 0; e < 6; e++) IO[e] += Iw[e] + m * ((ia[e] == ib[e] ? c2 : 0.0) - c[ia[e]] * c[ib[e]]);
 		mt += m;
 		UNROLL for (int a = 0; a < 3; a++) h[a] = fma(m, c[a], h[a]);
 		// wrench of the composite body under unit acceleration of joint k
@@ -604,15 +588,24 @@ DI void sandwich7(const real* Jp, const real* A, real* out) {
 // ------------------------------------------------------------------ SVD-free certificates
 // Certificate that a symmetric PSD Gram matrix G (n x n) restricted to the range it lives in has
 // lambda_max >= abs2 and lambda_min >= rel2 * lambda_max, i.e. for G = Jp Jp^T that s_0 >= sqrt(abs2)
-// and s_min / s_0 >= sqrt(rel2): lambda_max(G) <= ub := tr(G^2k)^(1/2k) <= n^(1/2k) lambda_max(G), and
+// and s_min / s_0 >= sqrt(rel2): lambda_max(G) <= ub := tr(G^8)^(1/8) <= n^(1/8) lambda_max(G), and
 // positive LDL^T pivots of G + ub Pc - rel2 ub I (Pc = projector onto the complement of the range, or
 // NULL when the range is everything) imply the bound. Sufficient, never necessary: whoever fails it
 // takes the Jacobi-SVD path, so decisions are the reference's in all cases.
 template <int n>
-DI bool ldl_positive(const real* G, const real* Pc, real ub, real rel2) {
+DI bool certify_gram(const real* G, const real* Pc, real abs2, real rel2) {
+	real G2[n * n], G4[n * n];
+	mm_nt_sym<n, n>(G, G, G2);	// G symmetric: G G^T = G^2
+	mm_nt_sym<n, n>(G2, G2, G4);
+	real t8 = 0;
+	UNROLL for (int i = 0; i < n; i++) UNROLL for (int j = 0; j <= i; j++) {
+		real v = G4[i * n + j] * G4[i * n + j];
+		t8 += (i == j) ? v : 2 * v;
+	}
+	const real ub = sqrt(sqrt(sqrt(t8)));
+	bool ok = ub > 1.28 * abs2;	 // lambda_max >= ub / n^(1/8), 7^(1/8) = 1.2754
 	const real c = rel2 * ub * (1.0 + 1e-9);
 	const real floor_ = 1e-5 * c;
-	bool ok = true;
 	real Lm[n * n], d[n];
 	UNROLL for (int j = 0; j < n; j++) {
 		real s = G[j * n + j] - c + (Pc ? ub * Pc[j * n + j] : 0.0);
@@ -627,30 +620,6 @@ DI bool ldl_positive(const real* G, const real* Pc, real ub, real rel2) {
 		}
 	}
 	return ok;
-}
-// Wavefront-level certificate (returns the same value in every lane): first with the cheaper bound
-// ub4 = tr(G^4)^(1/4) <= n^(1/4) lambda_max; only if some robot fails it, with the tighter
-// ub8 = tr(G^8)^(1/8) <= n^(1/8) lambda_max.
-template <int n>
-DI bool certify_gram_wave(const real* G, const real* Pc, real abs2, real rel2) {
-	real G2[n * n];
-	mm_nt_sym<n, n>(G, G, G2);	// G symmetric: G G^T = G^2
-	real t4 = 0;
-	UNROLL for (int i = 0; i < n; i++) UNROLL for (int j = 0; j <= i; j++) {
-		real v = G2[i * n + j] * G2[i * n + j];
-		t4 += (i == j) ? v : 2 * v;
-	}
-	const real ub4 = sqrt(sqrt(t4));
-	if (__all(ub4 > 1.63 * abs2 && ldl_positive<n>(G, Pc, ub4, rel2))) return true;	 // 7^(1/4) = 1.627
-	real G4[n * n];
-	mm_nt_sym<n, n>(G2, G2, G4);
-	real t8 = 0;
-	UNROLL for (int i = 0; i < n; i++) UNROLL for (int j = 0; j <= i; j++) {
-		real v = G4[i * n + j] * G4[i * n + j];
-		t8 += (i == j) ? v : 2 * v;
-	}
-	const real ub8 = sqrt(sqrt(sqrt(t8)));
-	return __all(ub8 > 1.28 * abs2 && ldl_positive<n>(G, Pc, ub8, rel2));  // 7^(1/8) = 1.2754
 }
 
 // Row space accumulated over the certified tasks of the hierarchy: W stacks the (full-row-rank)
@@ -699,7 +668,7 @@ DI void mft_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B
 		real G[36], Pc[36];
 		mm_nt_sym<6, N>(Jp, Jp, G);
 		UNROLL for (int i = 0; i < 6; i++) UNROLL for (int j = 0; j < 6; j++) Pc[i * 6 + j] = ((i == j) ? 1.0 : 0.0) - t.P[i * 6 + j];
-		certified = certify_gram_wave<6>(G, t.full_projection ? nullptr : Pc, t.s_abs_tol * t.s_abs_tol, t.s_max * t.s_max);
+		certified = __all(certify_gram<6>(G, t.full_projection ? nullptr : Pc, t.s_abs_tol * t.s_abs_tol, t.s_max * t.s_max));
 	}
 	real Q[N * 6], W[36], sv[6], ss[6], Pns[36], Ps[36], alpha = 1;
 	int pos[6], split = rank;
@@ -1075,7 +1044,7 @@ DI void jt_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B,
 		mm_nt_sym<N, N>(Jp, Jp, C0);
 		UNROLL for (int i = 0; i < N * N; i++) Pc[i] = 0;
 		UNROLL for (int i = 0; i < N; i++) Pc[i * N + i] = (i < t.k0) ? 0.0 : 1.0;
-		if (certify_gram_wave<N>(C0, Pc, 1e-6, 1e-6)) {
+		if (__all(certify_gram<N>(C0, Pc, 1e-6, 1e-6))) {
 			UNROLL for (int i = 0; i < N * N; i++) PR[i] = 0;
 			UNROLL for (int i = 0; i < N; i++) PR[i * N + i] = (i < t.k0) ? 1.0 : 0.0;
 			if (chain.ok) chain_append(chain, Jp, t.k0);

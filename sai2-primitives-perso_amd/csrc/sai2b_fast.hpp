@@ -56,11 +56,11 @@ DI void solve_lower_t(const real* L, const real* dinv, real* x) {
 	}
 }
 
-// Wavefront-level certificate for "s_0 >= s_abs_tol and s_5 / s_0 >= s_max" on the 6 x 7 Jacobian.
-DI bool certify_nonsingular_wave(const real* J, real s_abs_tol, real s_max) {
+// Certificate for "s_0 >= s_abs_tol and s_5 / s_0 >= s_max" on the 6 x 7 Jacobian (see header).
+DI bool certify_nonsingular(const real* J, real s_abs_tol, real s_max) {
 	real G[36];
 	mm_nt_sym<6, N>(J, J, G);
-	return certify_gram_wave<6>(G, nullptr, s_abs_tol * s_abs_tol, s_max * s_max);
+	return certify_gram<6>(G, nullptr, s_abs_tol * s_abs_tol, s_max * s_max);
 }
 
 // Inputs of the second-level JointTask law after the early part (fast_jt_early): the PD(+I) unit
@@ -186,7 +186,6 @@ DI void fast_tick(const DevParams& P, const real* J, const real* M, const real* 
 				UNROLL for (int c = 0; c < 6; c++) s = fma(-Y[i * 6 + c], tk[c], s);
 				w[i] = s * wn;
 			}
-#ifndef SAI2B_NO_REORTH
 			{  // one re-orthogonalisation pass: w <- w - Y A^-1 Y^T w, renormalise
 				real cw[6];
 				UNROLL for (int c = 0; c < 6; c++) {
@@ -206,7 +205,6 @@ DI void fast_tick(const DevParams& P, const real* J, const real* M, const real* 
 				const real rn = rsqrt(nn);
 				UNROLL for (int i = 0; i < N; i++) w[i] *= rn;
 			}
-#endif
 			UNROLL for (int i = 0; i < N; i++) a[i] = w[i];
 			solve_lower_t<N>(L, dL, a);	 // a = L^-T w
 			UNROLL for (int i = 0; i < N; i++) {

@@ -530,9 +530,6 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 		for (int k = 0; k < 3; k++) hp.model.xyz[i][k] = model->joint_xyz[i][k], hp.model.com[i][k] = model->link_com[i][k];
 		for (int k = 0; k < 6; k++) hp.model.inertia[i][k] = model->link_inertia[i][k];
 		hp.model.mass[i] = model->link_mass[i];
-		const double* li = model->link_inertia[i];
-		const bool diag = li[3] == 0 && li[4] == 0 && li[5] == 0;
-		hp.model.inertia_kind[i] = !diag ? 0 : ((li[0] == li[1] && li[1] == li[2]) ? 2 : 1);
 		hp.model.q_lower[i] = model->q_lower[i], hp.model.q_upper[i] = model->q_upper[i], hp.model.effort[i] = model->effort[i];
 	}
 	for (int k = 0; k < 3; k++) hp.model.gravity[k] = model->gravity[k];

@@ -124,8 +124,8 @@ __global__ __launch_bounds__(64) void tick_fast_kernel(const DevParams* __restri
 		}
 	}
 	SAI2B_PHASE();
-	const bool all_clean = __all(clean);
-	const bool all_ok = certify_nonsingular_wave(J, t0.s_abs_tol, t0.s_max) && all_clean;
+	const bool ok = certify_nonsingular(J, t0.s_abs_tol, t0.s_max);
+	const bool all_ok = __all(ok && clean);
 	if (threadIdx.x == 0) ((gint*)wave_flags)[blockIdx.x] = all_ok ? 0 : 1;
 	if (!all_ok) return;
 	// committed to the fast path: integrators can go out now

@@ -15,8 +15,6 @@ struct DevModel {
 	double mass[N];
 	double com[N][3];
 	double inertia[N][6]; // ixx iyy izz ixy ixz iyz at the COM, link axes
-	int inertia_kind[N];  // 0 general, 1 diagonal, 2 isotropic (lets the CRBA skip rotations)
-	int pad_;
 	double q_lower[N], q_upper[N], effort[N];
 	double gravity[3];
 };
