@@ -402,3 +402,42 @@ def test_device_resident_inputs_and_outputs():
     assert _err(out.cpu().numpy(), o.tick()).max() < TOL
     with pytest.raises(ValueError, match="mixing"):
         g.set_state(dev(inp["q"]), inp["dq"])
+
+
+def test_long_run_history_wraps_and_integrators_follow_oracle():
+    """260 ticks with moving robots, integral gains on, closed-loop... the 200-deep singularity history
+    ring wraps, type decisions flip, integrators accumulate: torques must follow the oracle every tick"""
+    B = 64
+    inp = pkg.workloads.make_inputs(3, B=B, seed=17)
+    rng = np.random.default_rng(3)
+    q0 = inp["q"].copy()
+    q0[3, :24] = rng.uniform(-0.10, -0.072, size=24)  # elbow nearly extended
+    q0[5, 24:48] = rng.uniform(0.0, 0.04, size=24)  # wrist nearly aligned
+    amp = rng.uniform(0.0, 0.03, size=(N, B))
+    phase = rng.uniform(0, 2 * np.pi, size=(N, B))
+    opts = [{"ki_pos": 4.0, "ki_ori": 2.0}, {"ki": 3.0}]
+    o, g = _pair(inp, opts, introspection=False)
+    ol.load_inputs(o, inp)
+    ol.load_inputs(g, inp)
+    worst, sing_ticks, flips = 0.0, 0, 0
+    prev_c1 = None
+    for t in range(260):
+        w = 2 * np.pi * t / 97.0
+        q = q0 + amp * np.sin(w + phase)
+        q = np.clip(q, pkg.workloads.PANDA_LOWER[:, None] + 1e-3, pkg.workloads.PANDA_UPPER[:, None] - 1e-3)
+        dq = amp * np.cos(w + phase) * (2 * np.pi / 97.0) / 1e-3 * 1e-3
+        o.set_state(q, dq)
+        g.set_state(q, dq)
+        tau_o, tau_g = o.tick(), g.tick()
+        _, _, ro = o.get_mft_singularity(0)
+        _, c1, c2 = o.get_mft_sh_state(0)
+        sing_ticks += int((ro < 6).sum())
+        if prev_c1 is not None:
+            flips += int(((c1 > c2) != prev_c1).sum())
+        prev_c1 = c1 > c2
+        e = _err(tau_g, tau_o)
+        assert e[ro == 6].max() < 10 * TOL, (t, e[ro == 6].max())
+        worst = max(worst, e.max())
+        assert e.max() < 1e-5, (t, e.max())
+    assert sing_ticks > 2000, "the run should spend many robot-ticks in the singular branches"
+    assert (c1 + c2).max() == 200, "history ring must have wrapped (cap 200)"
