@@ -235,6 +235,10 @@ int sai2b_get_task_torques(sai2b_ctx* ctx, int task, double* tau_task);
 /* MFT: singular values [6][B], blending alpha [B], split index (non-singular rank) [B] as doubles */
 int sai2b_get_mft_singularity(sai2b_ctx* ctx, int task, double* sigma, double* alpha,
 							  double* ns_rank);
+/* MFT: unit-mass motion force and force-related terms of the last tick, [6][B] each — what
+ * MotionForceTask::getUnitMassForce and the observers of POPCBilateralTeleoperation.cpp:81-92,172-182
+ * read (MotionForceTask.cpp:478-487) */
+int sai2b_get_mft_task_forces(sai2b_ctx* ctx, int task, double* F_unit, double* F_force);
 /* Sai2Model::M(): [49][B]; J of MFT `task` (JWorldFrame): [42][B]; position [3][B], rotation [9][B] */
 int sai2b_get_model(sai2b_ctx* ctx, int task, double* M, double* J, double* pos, double* rot);
 

@@ -539,6 +539,7 @@ typedef struct {
 	int hist_head, hist_size, c1, c2;
 	double q_prior[N7], dq_prior[N7], t2dir[N7];
 	double tau[N7];
+	double Fu[6], Ff[6];
 } mft_t;
 
 struct oracle_ctx {
@@ -1129,6 +1130,8 @@ static void mft_torques(const oracle_ctx* c, const sai2b_task_config* t, const r
 		Ff[i] = f_force[i] + ff[i];
 		Ff[3 + i] = f_moment[i] + ff[3 + i];
 	}
+	memcpy(s->Fu, Fu, sizeof(Fu));
+	memcpy(s->Ff, Ff, sizeof(Ff));
 	sh_torques(c, t, r, s, Fu, Ff, tau);
 }
 
@@ -1425,6 +1428,15 @@ int oracle_get_mft_lambda(oracle_ctx* c, int task, double* L_full, double* Lmod_
 			if (Lmod_full) Lmod_full[i * c->B + b] = Bm[i];
 		}
 	}
+	return 0;
+}
+int oracle_get_mft_task_forces(oracle_ctx* c, int task, double* Fu, double* Ff) {
+	if (task < 0 || task >= c->T || !c->mft[task]) return fail("not a MotionForceTask");
+	for (int b = 0; b < c->B; b++)
+		for (int i = 0; i < 6; i++) {
+			if (Fu) Fu[i * c->B + b] = c->mft[task][b].Fu[i];
+			if (Ff) Ff[i * c->B + b] = c->mft[task][b].Ff[i];
+		}
 	return 0;
 }
 int oracle_get_mft_sh_state(oracle_ctx* c, int task, double* first_type, double* c1, double* c2) {

@@ -78,6 +78,8 @@ int oracle_get_gravity(oracle_ctx* ctx, double* g);
 /* MFT: Lambda_ns embedded as U_ns Lambda_ns U_ns^T [36][B], same for the modified one */
 int oracle_get_mft_lambda(oracle_ctx* ctx, int task, double* Lambda_ns_full,
 						  double* Lambda_ns_mod_full);
+/* MFT: F_unit and F_force of the last computeTorques, [6][B] each */
+int oracle_get_mft_task_forces(oracle_ctx* ctx, int task, double* F_unit, double* F_force);
 /* MFT singularity classification of the last update: type per robot (0 none, 1 type-1, 2 type-2
  * of the first singular column), type-1 and type-2 counters; as doubles, [B] each */
 int oracle_get_mft_sh_state(oracle_ctx* ctx, int task, double* first_type, double* c1, double* c2);

@@ -237,6 +237,11 @@ class Controller:
         self._rc(self.lib.sai2b_get_mft_singularity(self.h, task, *[C.c_void_p(x.ctypes.data) for x in (s, a, r)]))
         return s, a, r
 
+    def get_mft_task_forces(self, task):
+        fu, ff = np.empty((6, self.B)), np.empty((6, self.B))
+        self._rc(self.lib.sai2b_get_mft_task_forces(self.h, task, C.c_void_p(fu.ctypes.data), C.c_void_p(ff.ctypes.data)))
+        return fu, ff
+
     def get_model(self, task=-1):
         M = np.empty((DOF * DOF, self.B))
         if task < 0:
@@ -510,6 +515,10 @@ class MotionForceTask(_TaskBase):
     def setSingularityHandlingBounds(self, s_min, s_max):
         self._cfg.s_min, self._cfg.s_max = float(s_min), float(s_max)
         self._sync_cfg()
+
+    def getUnitMassForce(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_task_forces(idx)[0]
 
     def getSigmaValues(self):
         rc, idx = self._require_owner()

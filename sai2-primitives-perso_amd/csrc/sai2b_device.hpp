@@ -983,6 +983,12 @@ DI void mft_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B
 		if (t.dbg_J) {
 			UNROLL for (int i = 0; i < 6 * N; i++) st(t.dbg_J, i, B, b, Jw[i]);
 		}
+		if (t.dbg_F) {
+			UNROLL for (int i = 0; i < 6; i++) {
+				st(t.dbg_F, i, B, b, Fu[i]);
+				st(t.dbg_F, 6 + i, B, b, Ff[i]);
+			}
+		}
 		if (t.dbg_pose) {
 			UNROLL for (int i = 0; i < 3; i++) st(t.dbg_pose, i, B, b, x[i]);
 			UNROLL for (int i = 0; i < 9; i++) st(t.dbg_pose, 3 + i, B, b, R[i]);

@@ -615,6 +615,7 @@ extern "C" int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_ta
 	fill_dev_task(*cfg, d);
 	d.goals = keep.goals, d.sensed = keep.sensed, d.state = keep.state, d.istate = keep.istate;
 	d.dbg_tau = keep.dbg_tau, d.dbg_N = keep.dbg_N, d.dbg_sigma = keep.dbg_sigma, d.dbg_J = keep.dbg_J, d.dbg_pose = keep.dbg_pose;
+	d.dbg_F = keep.dbg_F;
 	ctx->params_dirty = true;
 	return SAI2B_OK;
 }
@@ -803,6 +804,7 @@ extern "C" int sai2b_enable_introspection(sai2b_ctx* ctx, int enable) {
 				if ((rc = dev_alloc(ctx, &d.dbg_sigma, 8 * B))) return rc;
 				if ((rc = dev_alloc(ctx, &d.dbg_J, 6 * N * B))) return rc;
 				if ((rc = dev_alloc(ctx, &d.dbg_pose, 12 * B))) return rc;
+				if ((rc = dev_alloc(ctx, &d.dbg_F, 12 * B))) return rc;
 			}
 		}
 		ctx->params_dirty = true;
@@ -837,6 +839,13 @@ extern "C" int sai2b_get_mft_singularity(sai2b_ctx* ctx, int task, double* sigma
 	if ((rc = fetch_dbg(ctx, sigma, s, 6))) return rc;
 	if ((rc = fetch_dbg(ctx, alpha, s ? s + 6 * B : nullptr, 1))) return rc;
 	return fetch_dbg(ctx, ns_rank, s ? s + 7 * B : nullptr, 1);
+}
+extern "C" int sai2b_get_mft_task_forces(sai2b_ctx* ctx, int task, double* F_unit, double* F_force) {
+	int rc = mft_task_check(ctx, task, "sai2b_get_mft_task_forces");
+	if (rc) return rc;
+	const double* F = ctx->h_params.task[task].dbg_F;
+	if ((rc = fetch_dbg(ctx, F_unit, F, 6))) return rc;
+	return fetch_dbg(ctx, F_force, F ? F + 6 * (size_t)ctx->B : nullptr, 6);
 }
 extern "C" int sai2b_get_model(sai2b_ctx* ctx, int task, double* M, double* J, double* pos, double* rot) {
 	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");

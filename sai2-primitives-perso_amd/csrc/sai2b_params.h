@@ -65,6 +65,7 @@ struct DevTask {
 	double* dbg_sigma;	// [8][B] sigma0..5, alpha, ns
 	double* dbg_J;		// [42][B] JWorldFrame
 	double* dbg_pose;	// [12][B] pos3 rot9
+	double* dbg_F;		// [12][B] F_unit 6, F_force 6 (MotionForceTask.cpp:478-487)
 };
 
 constexpr int MFT_GOAL_ROWS = 30;

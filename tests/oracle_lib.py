@@ -59,6 +59,7 @@ def lib():
     L.oracle_get_gravity.argtypes = [vp, vp]
     L.oracle_get_mft_lambda.argtypes = [vp, i, vp, vp]
     L.oracle_get_mft_sh_state.argtypes = [vp, i, vp, vp, vp]
+    L.oracle_get_mft_task_forces.argtypes = [vp, i, vp, vp]
     L.oracle_get_jt_inertia.argtypes = [vp, i, vp, vp]
     L.oracle_svd.argtypes = [i, i, vp, vp, vp, vp]
     L.oracle_svd.restype = None
@@ -252,6 +253,11 @@ class Oracle:
     def get_mft_lambda(self, task):
         a, b = np.empty((36, self.B)), np.empty((36, self.B))
         assert self.L.oracle_get_mft_lambda(self.h, task, _ptr(a), _ptr(b)) == 0
+        return a, b
+
+    def get_mft_task_forces(self, task):
+        a, b = np.empty((6, self.B)), np.empty((6, self.B))
+        assert self.L.oracle_get_mft_task_forces(self.h, task, _ptr(a), _ptr(b)) == 0
         return a, b
 
     def get_mft_sh_state(self, task):

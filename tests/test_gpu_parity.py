@@ -49,6 +49,8 @@ def test_gpu_matches_oracle_and_golden(name):
             assert np.array_equal(ro, rg), "branch disagreement"
             assert np.abs(so - sg).max() < 1e-12 and np.abs(ao - ag).max() < 1e-10
             singular |= ro < (o.tasks[t].pos_range + o.tasks[t].ori_range)
+            for fo, fg in zip(o.get_mft_task_forces(t), g.get_mft_task_forces(t)):
+                assert np.abs(fo - fg).max() < 1e-10 * max(1.0, np.abs(fo).max())
             Mo, Jo, xo, Ro = o.get_model(t)
             Mg, Jg, xg, Rg = g.get_model(t)
             assert np.abs(Jo - Jg).max() < 1e-13 and np.abs(xo - xg).max() < 1e-13 and np.abs(Ro - Rg).max() < 1e-13
