@@ -103,6 +103,7 @@ typedef struct sai2b_task_config {
 	double kff_force, kff_moment;
 	double max_force_feedback, max_moment_feedback;
 	int closed_loop_force, closed_loop_moment;
+	int passivity_enabled; /* MotionForceTask::enablePassivity (MotionForceTask.h:629): POPC on the force loop */
 	int force_space_dimension, moment_space_dimension;
 	double force_axis[3], moment_axis[3];
 	double linear_saturation_velocity, angular_saturation_velocity;

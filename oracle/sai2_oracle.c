@@ -18,6 +18,7 @@
 
 #define N7 SAI2B_DOF
 #define MAXD 7 /* largest matrix dimension anywhere on the path */
+#define POPC_RING 1024 /* window ring capacity (the reference queue is unbounded; same cap as the product) */
 
 static char g_err[512] = "";
 const char* oracle_last_error(void) { return g_err; }
@@ -540,6 +541,10 @@ typedef struct {
 	double q_prior[N7], dq_prior[N7], t2dir[N7];
 	double tau[N7];
 	double Fu[6], Ff[6];
+	/* POPCExplicitForceControl members (POPCExplicitForceControl.h:42-50) */
+	double popc_po, popc_ecorr, popc_vsum, popc_Rc;
+	int popc_counter, popc_head, popc_size;
+	double popc_ring[POPC_RING];
 } mft_t;
 
 struct oracle_ctx {
@@ -745,6 +750,59 @@ static void mft_reinit(const sai2b_task_config* t, const robot_t* r, mft_t* s) {
 		s->sens_f[i] = s->sens_m[i] = 0;
 		s->integ_pos[i] = s->integ_ori[i] = s->integ_f[i] = s->integ_m[i] = 0;
 	}
+}
+static void popc_init(mft_t* s) { /* POPCExplicitForceControl.cpp:10-22 */
+	s->popc_po = s->popc_ecorr = s->popc_vsum = 0;
+	s->popc_Rc = 1.0;
+	s->popc_counter = 50;
+	s->popc_head = s->popc_size = 0;
+}
+/* POPCExplicitForceControl::computePassivitySaturatedForce, observer enabled (POPCExplicitForceControl.cpp:37-95) */
+static void popc_force(const sai2b_task_config* t, mft_t* s, const double* fd, const double* fs, const double* vcl,
+					   const double* vr, double* out) {
+	double fcmd[3], vc2 = 0, p = 0;
+	for (int k = 0; k < 3; k++) {
+		fcmd[k] = t->kff_force * fd[k] + s->popc_Rc * vcl[k] - t->kv_force[k] * vr[k];
+		vc2 += vcl[k] * vcl[k];
+		p += (fs[k] - fd[k]) * vcl[k] - fcmd[k] * vr[k];
+	}
+	p *= t->loop_timestep;
+	s->popc_po += p;
+	if (s->popc_size == POPC_RING) { /* bounded stand-in for the unbounded std::queue */
+		double front = s->popc_ring[s->popc_head];
+		if (front > 0) s->popc_po -= front;
+		s->popc_head = (s->popc_head + 1) % POPC_RING;
+		s->popc_size--;
+	}
+	s->popc_ring[(s->popc_head + s->popc_size) % POPC_RING] = p;
+	s->popc_size++;
+	if (s->popc_po + s->popc_ecorr > 0) {
+		while (s->popc_size > 250) {
+			double front = s->popc_ring[s->popc_head];
+			if (s->popc_po + s->popc_ecorr > front) {
+				if (front > 0) s->popc_po -= front;
+				s->popc_head = (s->popc_head + 1) % POPC_RING;
+				s->popc_size--;
+			} else
+				break;
+		}
+	}
+	if (s->popc_counter <= 0) {
+		s->popc_counter = 50;
+		double old = s->popc_Rc;
+		if (s->popc_po + s->popc_ecorr < 0) {
+			s->popc_Rc = 1 + (s->popc_po + s->popc_ecorr) / (s->popc_vsum * t->loop_timestep);
+			if (s->popc_Rc > 1) s->popc_Rc = 1;
+			if (s->popc_Rc < 0) s->popc_Rc = 0;
+		} else {
+			s->popc_Rc = (1 + (0.1 * 50 - 1) * s->popc_Rc) / (0.1 * 50);
+		}
+		s->popc_ecorr += (1 - old) * s->popc_vsum * t->loop_timestep;
+		s->popc_vsum = 0;
+	}
+	s->popc_counter--;
+	s->popc_vsum += vc2;
+	for (int k = 0; k < 3; k++) out[k] = s->popc_Rc * vcl[k] - t->kv_force[k] * vr[k];
 }
 static void sh_init(const oracle_ctx* c, mft_t* s) {
 	s->n_types = 0;
@@ -1049,7 +1107,14 @@ static void mft_torques(const oracle_ctx* c, const sai2b_task_config* t, const r
 		double vcl[3], vr[3];
 		mv3(sf, fb, vcl);
 		mv3(sf, v, vr);
-		for (int i = 0; i < 3; i++) f_force[i] = vcl[i] - t->kv_force[i] * vr[i];
+		if (t->passivity_enabled) {
+			double fd[3], fsf[3];
+			mv3(sf, gf, fd);
+			mv3(sf, fs_w, fsf);
+			popc_force(t, s, fd, fsf, vcl, vr, f_force);
+		} else {
+			for (int i = 0; i < 3; i++) f_force[i] = vcl[i] - t->kv_force[i] * vr[i];
+		}
 	} else {
 		for (int i = 0; i < 3; i++) e[i] = -t->kv_force[i] * v[i];
 		mv3(sf, e, f_force);
@@ -1186,6 +1251,7 @@ oracle_ctx* oracle_create(const sai2b_robot_model* model, const sai2b_task_confi
 			} else {
 				mft_reinit(&c->cfg[i], &c->robots[b], &c->mft[i][b]);
 				sh_init(c, &c->mft[i][b]);
+				popc_init(&c->mft[i][b]);
 				eye(N7, c->mft[i][b].N_prec);
 			}
 		}
@@ -1206,6 +1272,8 @@ int oracle_update_task_config(oracle_ctx* c, int task, const sai2b_task_config* 
 	if (!c || task < 0 || task >= c->T || !cfg || cfg->type != c->cfg[task].type ||
 		cfg->task_dof != c->cfg[task].task_dof)
 		return fail("update_task_config: bad arguments");
+	if (c->mft[task] && (cfg->passivity_enabled != 0) != (c->cfg[task].passivity_enabled != 0))
+		for (int b = 0; b < c->B; b++) popc_init(&c->mft[task][b]); /* enable()/disable() */
 	c->cfg[task] = *cfg;
 	return 0;
 }

@@ -84,6 +84,7 @@ class TaskConfig(C.Structure):
         ("max_moment_feedback", _d),
         ("closed_loop_force", _i),
         ("closed_loop_moment", _i),
+        ("passivity_enabled", _i),
         ("force_space_dimension", _i),
         ("moment_space_dimension", _i),
         ("force_axis", _d * 3),

@@ -409,8 +409,72 @@ DI void mft_store_integrators(const DevTask& t, int B, int b, const MftIn& in) {
 // MotionForceTask::computeTorques() control law up to the task forces (MotionForceTask.cpp:278-503).
 // Produces F_unit (unit-mass motion force) and F_force (force-related terms + feed-forward).
 // The integrators in `in.integ` are advanced in place; mft_store_integrators() writes them back.
+// POPCExplicitForceControl::computePassivitySaturatedForce with the observer ENABLED
+// (POPCExplicitForceControl.cpp:37-95): windowed passivity observer on the force loop and the
+// controller scaling Rc re-evaluated every 50 ticks. State per robot in t.popc_*; committed only when
+// `commit`. The reference's std::queue is unbounded; the ring holds POPC_RING samples and, if a robot
+// stays active longer than that, retires the oldest sample as the reference's pop would.
+DI void popc_force(const DevTask& t, int B, int b, bool commit, const real* fd, const real* fs, const real* vcl,
+				   const real* vr, real* out) {
+	real po = ld(t.popc_f, 0, B, b), ecorr = ld(t.popc_f, 1, B, b), vsum = ld(t.popc_f, 2, B, b), Rc = ld(t.popc_f, 3, B, b);
+	int counter = ldi(t.popc_i, 0, B, b), head = ldi(t.popc_i, 1, B, b), size = ldi(t.popc_i, 2, B, b);
+	real fcmd[3], vc2 = 0, p_in = 0;
+	UNROLL for (int k = 0; k < 3; k++) {
+		fcmd[k] = t.kff_f * fd[k] + Rc * vcl[k] - t.kv_f[k] * vr[k];
+		vc2 = fma(vcl[k], vcl[k], vc2);
+		p_in += (fs[k] - fd[k]) * vcl[k] - fcmd[k] * vr[k];
+	}
+	p_in *= t.dt;
+	po += p_in;
+	if (size == POPC_RING) {  // overflow: retire the oldest sample
+		const real front = ld(t.popc_q, head, B, b);
+		if (front > 0) po -= front;
+		head = (head + 1) % POPC_RING;
+		size--;
+	}
+	if (commit) st(t.popc_q, (head + size) % POPC_RING, B, b, p_in);
+	real newest = p_in;	 // value at the back of the window (not yet visible in memory when !commit)
+	size++;
+	if (po + ecorr > 0) {
+		while (size > POPC_WINDOW) {
+			const real front = (size == 1) ? newest : ld(t.popc_q, head, B, b);
+			if (po + ecorr > front) {
+				if (front > 0) po -= front;
+				head = (head + 1) % POPC_RING;
+				size--;
+			} else {
+				break;
+			}
+		}
+	}
+	if (counter <= 0) {
+		counter = POPC_MAX_COUNTER;
+		const real old_Rc = Rc;
+		if (po + ecorr < 0) {
+			Rc = 1 + (po + ecorr) / (vsum * t.dt);
+			Rc = (Rc > 1) ? 1.0 : ((Rc < 0) ? 0.0 : Rc);
+		} else {
+			Rc = (1 + (0.1 * POPC_MAX_COUNTER - 1) * Rc) / (0.1 * POPC_MAX_COUNTER);
+		}
+		ecorr += (1 - old_Rc) * vsum * t.dt;
+		vsum = 0;
+	}
+	counter--;
+	vsum += vc2;
+	UNROLL for (int k = 0; k < 3; k++) out[k] = Rc * vcl[k] - t.kv_f[k] * vr[k];
+	if (commit) {
+		st(t.popc_f, 0, B, b, po);
+		st(t.popc_f, 1, B, b, ecorr);
+		st(t.popc_f, 2, B, b, vsum);
+		st(t.popc_f, 3, B, b, Rc);
+		sti(t.popc_i, 0, B, b, counter);
+		sti(t.popc_i, 1, B, b, head);
+		sti(t.popc_i, 2, B, b, size);
+	}
+}
+
 DI void mft_law(const DevTask& t, const RobotCtx& rc, const real* J, const real* x, const real* R, MftIn& in, real* Fu,
-				real* Ff) {
+				real* Ff, int B = 0, int b = 0, bool commit = false) {
 	real v[3], w[3];
 	mv<3, N>(J, rc.dq, v);
 	mv<3, N>(J + 3 * N, rc.dq, w);
@@ -483,7 +547,14 @@ DI void mft_law(const DevTask& t, const RobotCtx& rc, const real* J, const real*
 		}
 		mv3(sf, fb, vcl);
 		mv3(sf, v, vr);
-		UNROLL for (int k = 0; k < 3; k++) f_force[k] = vcl[k] - t.kv_f[k] * vr[k];
+		if (t.passivity) {
+			real fd[3], fs[3];
+			mv3(sf, gf, fd);
+			mv3(sf, fs_w, fs);
+			popc_force(t, B, b, commit, fd, fs, vcl, vr, f_force);
+		} else {
+			UNROLL for (int k = 0; k < 3; k++) f_force[k] = vcl[k] - t.kv_f[k] * vr[k];
+		}
 	} else {
 		UNROLL for (int k = 0; k < 3; k++) e[k] = -t.kv_f[k] * v[k];
 		mv3(sf, e, f_force);
@@ -765,7 +836,7 @@ DI void mft_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B
 	{
 		MftIn in;
 		mft_load(t, B, b, in);
-		mft_law(t, rc, J, x, R, in, Fu, Ff);
+		mft_law(t, rc, J, x, R, in, Fu, Ff, B, b, do_torque);
 		if (do_torque) mft_store_integrators(t, B, b, in);
 	}
 	real tau[N];

@@ -453,6 +453,7 @@ static void fill_dev_task(const sai2b_task_config& c, DevTask& d) {
 	std::memcpy(d.sensor_rot, c.sensor_rot, sizeof(d.sensor_rot));
 	d.kff_f = c.kff_force, d.kff_m = c.kff_moment, d.max_f = c.max_force_feedback, d.max_m = c.max_moment_feedback;
 	d.cl_force = c.closed_loop_force, d.cl_moment = c.closed_loop_moment;
+	d.passivity = c.passivity_enabled;
 	d.fdim = c.force_space_dimension, d.mdim = c.moment_space_dimension;
 	d.lin_vsat = c.linear_saturation_velocity, d.ang_vsat = c.angular_saturation_velocity;
 	d.plain_motion = (d.full_projection && d.fdim == 0 && d.mdim == 0 && !d.use_vsat) ? 1 : 0;
@@ -498,6 +499,28 @@ static int dev_alloc(sai2b_ctx* ctx, T** p, size_t count) {
 	HIP_TRY(ctx, hipMemsetAsync(v, 0, std::max<size_t>(count, 1) * sizeof(T), ctx->stream));
 	ctx->allocs.push_back(v);
 	*p = (T*)v;
+	return SAI2B_OK;
+}
+
+// POPCExplicitForceControl::reInitialize (POPCExplicitForceControl.cpp:10-22) for every robot of a task;
+// buffers are created on first use (1024-sample window ring per robot)
+static int popc_reinit(sai2b_ctx* ctx, int task) {
+	DevTask& d = ctx->h_params.task[task];
+	const size_t B = ctx->B;
+	int rc;
+	if (!d.popc_f) {
+		if ((rc = dev_alloc(ctx, &d.popc_f, 4 * B))) return rc;
+		if ((rc = dev_alloc(ctx, &d.popc_i, 3 * B))) return rc;
+		if ((rc = dev_alloc(ctx, &d.popc_q, (size_t)sai2b::POPC_RING * B))) return rc;
+		ctx->params_dirty = true;
+	}
+	std::vector<double> f(4 * B, 0.0);
+	std::fill(f.begin() + 3 * B, f.end(), 1.0);	 // Rc = 1
+	std::vector<int> iv(3 * B, 0);
+	std::fill(iv.begin(), iv.begin() + B, sai2b::POPC_MAX_COUNTER);
+	HIP_TRY(ctx, hipMemcpyAsync(d.popc_f, f.data(), f.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(d.popc_i, iv.data(), iv.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return SAI2B_OK;
 }
 
@@ -555,6 +578,8 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 			if ((rc = dev_alloc(ctx, &d.state, (size_t)d.k0 * Bs))) return rc;
 		}
 	}
+	for (int t = 0; t < n_tasks; t++)
+		if (tasks[t].type == SAI2B_MOTION_FORCE_TASK && tasks[t].passivity_enabled && (rc = popc_reinit(ctx, t))) return rc;
 	ctx->params_dirty = true;
 	if ((rc = upload_params(ctx))) return rc;
 	// the reference constructs tasks from the model's current state (q = 0 until set_state)
@@ -609,10 +634,18 @@ extern "C" int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_ta
 	all[task] = *cfg;
 	char msg[256];
 	if (sai2b_validate_tasks(all, ctx->T, msg, sizeof(msg))) return set_error(ctx, SAI2B_INVALID_ARGUMENT, msg);
+	const bool popc_toggle = old.type == SAI2B_MOTION_FORCE_TASK && (cfg->passivity_enabled != 0) != (old.passivity_enabled != 0);
 	ctx->cfg[task] = *cfg;
 	DevTask& d = ctx->h_params.task[task];
 	DevTask keep = d;
 	fill_dev_task(*cfg, d);
+	d.popc_f = keep.popc_f, d.popc_i = keep.popc_i, d.popc_q = keep.popc_q;
+	// enable(): just switches on; disable(): also reinitialises (POPCExplicitForceControl.cpp:24-28).
+	// Buffers must exist before the first enabled tick.
+	if (popc_toggle || (cfg->passivity_enabled && !d.popc_f)) {
+		int rc2 = popc_reinit(ctx, task);
+		if (rc2) return rc2;
+	}
 	d.goals = keep.goals, d.sensed = keep.sensed, d.state = keep.state, d.istate = keep.istate;
 	d.dbg_tau = keep.dbg_tau, d.dbg_N = keep.dbg_N, d.dbg_sigma = keep.dbg_sigma, d.dbg_J = keep.dbg_J, d.dbg_pose = keep.dbg_pose;
 	d.dbg_F = keep.dbg_F;
@@ -710,6 +743,8 @@ extern "C" int sai2b_reinitialize(sai2b_ctx* ctx) {
 
 // eligibility of the SVD-free path (sai2b_fast.hpp): [full MFT] or [full MFT, full JT]; whole wavefronts only
 static int fast_kind(const sai2b_ctx* ctx) {
+	// the passivity observer mutates per-robot state inside the law: generic kernel only
+	if (ctx->cfg[0].passivity_enabled && ctx->cfg[0].closed_loop_force) return 0;
 	if (ctx->no_fast_path || ctx->T > 2 || ctx->B % 64 != 0 || ctx->cfg[0].type != SAI2B_MOTION_FORCE_TASK ||
 		!ctx->h_params.task[0].full_projection || ctx->h_params.task[0].rank != 6)
 		return 0;

@@ -45,6 +45,7 @@ struct DevTask {
 	double kp_f[3], kv_f[3], ki_f[3], kp_m[3], kv_m[3], ki_m[3];
 	double kff_f, kff_m, max_f, max_m;
 	int cl_force, cl_moment, fdim, mdim;
+	int passivity;	// POPC enabled on the closed-loop force term (POPCExplicitForceControl.cpp:37-95)
 	double faxis[3], maxis[3];
 	double sig[4][9];  // sigmaForce, sigmaPosition, sigmaMoment, sigmaOrientation when !in_frame
 	double lin_vsat, ang_vsat;
@@ -59,6 +60,9 @@ struct DevTask {
 	double* sensed; // MFT [6][B]
 	double* state;	// MFT [33][B]: integ pos3 ori3 f3 m3, q_prior7, dq_prior7, t2dir7 ; JT [k0][B]
 	int* istate;	// MFT [12][B]: hist words 0..6, n_types, count, size, c1, c2
+	double* popc_f; // MFT, passivity only: [4][B] PO value, E_correction, sum |vcl|^2, Rc
+	int* popc_i;	// [3][B] PO counter, ring head, ring size
+	double* popc_q; // [POPC_RING][B] windowed power samples
 	// optional introspection outputs (NULL unless debug outputs are enabled)
 	double* dbg_tau;	// [7][B]
 	double* dbg_N;		// [49][B] N * N_prec
@@ -71,6 +75,8 @@ struct DevTask {
 constexpr int MFT_GOAL_ROWS = 30;
 constexpr int MFT_STATE_ROWS = 33;
 constexpr int MFT_ISTATE_ROWS = 12;
+constexpr int POPC_RING = 1024;	 // capacity of the PO window ring (the reference queue is unbounded)
+constexpr int POPC_WINDOW = 250, POPC_MAX_COUNTER = 50;	 // POPCExplicitForceControl.h:38-39
 // istate rows
 constexpr int IS_NTYPES = 7, IS_COUNT = 8, IS_SIZE = 9, IS_C1 = 10, IS_C2 = 11;
 

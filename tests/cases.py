@@ -65,6 +65,8 @@ def apply_opts(cfg, opts):
             setattr(cfg, k, int(v))
         elif k == "in_compliant_frame":
             cfg.parametrization_in_compliant_frame = int(v)
+        elif k == "passivity":
+            cfg.passivity_enabled = int(v)
         elif k == "enforce_type_1":
             cfg.enforce_type_1_strategy = int(v)
         elif k == "enforce_handling":
@@ -80,12 +82,17 @@ def run_case_on(ctrl, inp, kw, z):
 
     load_inputs(ctrl, inp)
     if "in_wrench_f" in z:
-        ctrl.set_mft_goal_wrench(0, z["in_wrench_f"], z["in_wrench_m"])
-        ctrl.set_mft_sensed_wrench(0, z["in_wrench_sf"], z["in_wrench_sm"])
+        B = inp["B"]
+        ctrl.set_mft_goal_wrench(0, z["in_wrench_f"][:, :B], z["in_wrench_m"][:, :B])
+        ctrl.set_mft_sensed_wrench(0, z["in_wrench_sf"][:, :B], z["in_wrench_sm"][:, :B])
     if kw.get("gravity_comp"):
         ctrl.enable_gravity_compensation(True)
     tau = None
-    for _ in range(kw.get("ticks", 1)):
+    for tick in range(kw.get("ticks", 1)):
+        if kw.get("tick_inputs") == "popc":
+            dq_t, sf_t, sm_t = make_golden.popc_tick_inputs(tick, inp["B"], z["in_wrench_f"])
+            ctrl.set_state(inp["q"], dq_t)
+            ctrl.set_mft_sensed_wrench(0, sf_t, sm_t)
         ctrl.update_task_models()
         tau = ctrl.compute_control_torques(with_compensation=kw.get("with_comp", True))
     return tau

@@ -288,6 +288,8 @@ class MotionForceTaskNP:
         self.kp_m, self.kv_m, self.ki_m = np.full(3, 0.7), np.full(3, 10.0), np.full(3, 1.3)
         self.kff_f = self.kff_m = 0.95
         self.max_f, self.max_m = 20.0, 10.0
+        self.passivity = opt.get("passivity", False)
+        self.po, self.ecorr, self.vsum, self.Rc, self.po_counter, self.po_window = 0.0, 0.0, 0.0, 1.0, 50, []
         self.cl_f = opt.get("closed_loop_force", False)
         self.cl_m = opt.get("closed_loop_moment", False)
         self.fdim = opt.get("force_space_dimension", 0)
@@ -460,7 +462,10 @@ class MotionForceTaskNP:
             n = np.linalg.norm(fb)
             if n > self.max_f:
                 fb = fb * self.max_f / n
-            f_force = sf @ fb - self.kv_f * (sf @ v)
+            if self.passivity:
+                f_force = self.popc(sf @ gf, sf @ fs_w, sf @ fb, sf @ v)
+            else:
+                f_force = sf @ fb - self.kv_f * (sf @ v)
         else:
             f_force = sf @ (-self.kv_f * v)
         if self.cl_m:
@@ -503,6 +508,33 @@ class MotionForceTaskNP:
         Ff = np.concatenate([f_force, f_moment]) + ff
         self.Fu, self.Ff = Fu, Ff
         return self.sh_torques(Fu, Ff)
+
+    def popc(self, fd, fs, vcl, vr):
+        """POPCExplicitForceControl.cpp:37-95 (observer enabled)"""
+        F_cmd = self.kff_f * fd + self.Rc * vcl - self.kv_f * vr
+        p = ((fs - fd) @ vcl - F_cmd @ vr) * self.dt
+        self.po += p
+        self.po_window.append(p)
+        if self.po + self.ecorr > 0:
+            while len(self.po_window) > 250:
+                if self.po + self.ecorr > self.po_window[0]:
+                    if self.po_window[0] > 0:
+                        self.po -= self.po_window[0]
+                    self.po_window.pop(0)
+                else:
+                    break
+        if self.po_counter <= 0:
+            self.po_counter = 50
+            old = self.Rc
+            if self.po + self.ecorr < 0:
+                self.Rc = float(np.clip(1 + (self.po + self.ecorr) / (self.vsum * self.dt), 0, 1))
+            else:
+                self.Rc = (1 + (0.1 * 50 - 1) * self.Rc) / (0.1 * 50)
+            self.ecorr += (1 - old) * self.vsum * self.dt
+            self.vsum = 0.0
+        self.po_counter -= 1
+        self.vsum += vcl @ vcl
+        return self.Rc * vcl - self.kv_f * vr
 
     def sh_torques(self, Fu, Ff):
         rb = self.robot
@@ -555,7 +587,21 @@ def make_singular(inp):
     return inp
 
 
-def run_case(inp, task_opts=None, gravity_comp=False, with_comp=True, extra=None, ticks=1):
+def popc_tick_inputs(t, B, goal_f):
+    """deterministic per-tick joint velocities and sensed wrench for the passivity fixture: the sensed
+    force tracks the goal force closely (passive: damping dominates, the 250-sample window slides)
+    except during two bursts of large force error (activity: Rc drops below 1, then recovers)"""
+    b = np.arange(B)
+    dq = 0.8 * np.sin(0.05 * t + 0.3 * np.arange(N)[:, None] + 0.1 * b[None, :])
+    burst = 7.0 if (88 <= t < 100) or (238 <= t < 250) else 0.02
+    pat = np.stack([np.sin(0.31 * t + 0.2 * b), np.cos(0.17 * t + 0.1 * b), np.sin(0.23 * t + 0.05 * b)])
+    sf = goal_f[:, :B] + burst * pat
+    sm = np.stack([0.5 * np.sin(0.11 * t + b), 0.4 * np.cos(0.07 * t + b), 0.3 * np.sin(0.13 * t + 0.5 * b)])
+    return dq, sf, sm
+
+
+def run_case(inp, task_opts=None, gravity_comp=False, with_comp=True, extra=None, ticks=1, tick_inputs=None,
+             tick_goal_f=None):
     """Run the numpy restatement over all robots of a workloads.make_inputs() dict.
     extra(b, tasks) may install per-robot goal wrenches / sensed wrenches. Returns a dict of SoA
     outputs after `ticks` ticks (state is held fixed between ticks)."""
@@ -611,7 +657,11 @@ def run_case(inp, task_opts=None, gravity_comp=False, with_comp=True, extra=None
                 tk.goal_q, tk.goal_dq, tk.goal_ddq = g["q"][:, b].copy(), g["dq"][:, b].copy(), g["ddq"][:, b].copy()
         if extra:
             extra(b, tasks)
-        for _ in range(ticks):
+        for tick in range(ticks):
+            if tick_inputs == "popc":
+                dq_t, sf_t, sm_t = popc_tick_inputs(tick, B, tick_goal_f)
+                rb.dq = dq_t[:, b].copy()
+                tasks[0].sens_f, tasks[0].sens_m = sf_t[:, b].copy(), sm_t[:, b].copy()
             N_prec = np.eye(N)
             for tk in tasks:
                 tk.update(N_prec)
@@ -669,6 +719,11 @@ def cases():
     wrench = {"f": rng.normal(0, 5, size=(3, 64)), "m": rng.normal(0, 1, size=(3, 64)),
               "sf": rng.normal(0, 5, size=(3, 64)), "sm": rng.normal(0, 1, size=(3, 64))}
 
+    wrench_small = {k: 0.05 * v for k, v in wrench.items()}
+
+    def install_small_wrench(b, tasks):
+        tasks[0].g_f, tasks[0].g_m = wrench_small["f"][:, b].copy(), wrench_small["m"][:, b].copy()
+
     def install_wrench(b, tasks):
         tasks[0].g_f, tasks[0].g_m = wrench["f"][:, b].copy(), wrench["m"][:, b].copy()
         tasks[0].sens_f, tasks[0].sens_m = wrench["sf"][:, b].copy(), wrench["sm"][:, b].copy()
@@ -697,6 +752,11 @@ def cases():
         ("c3_singular_4ticks", 3, 96, None, {"ticks": 4, "prepare": "singular"}),
         ("c3_singular_type1_enforced", 3, 48, [{"enforce_type_1": True}, {}], {"ticks": 2, "prepare": "singular"}),
         ("c3_singular_no_handling", 3, 48, [{"enforce_handling": False}, {}], {"prepare": "singular"}),
+        # closed-loop force control with the passivity observer / controller enabled for 330 ticks
+        # (POPCExplicitForceControl.cpp:37-95): window of 250 fills and slides, Rc re-evaluated 6 times
+        ("c3_force_popc_330ticks", 3, 24, [{"force_space_dimension": 3, "closed_loop_force": True, "passivity": True}, {}],
+         {"extra": install_small_wrench, "wrench": wrench_small, "ticks": 330, "tick_inputs": "popc",
+          "tick_goal_f": wrench_small["f"]}),
     ]
 
 
