@@ -254,6 +254,15 @@ public:
 		_cfg.closed_loop_force = on;
 		syncConfig();
 	}
+	// MotionForceTask.h:626-630 (POPC on the closed-loop force term)
+	void enablePassivity() {
+		_cfg.passivity_enabled = 1;
+		syncConfig();
+	}
+	void disablePassivity() {
+		_cfg.passivity_enabled = 0;
+		syncConfig();
+	}
 	void setClosedLoopMomentControl(const bool on = true) {
 		_cfg.closed_loop_moment = on;
 		syncConfig();

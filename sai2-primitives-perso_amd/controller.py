@@ -494,6 +494,14 @@ class MotionForceTask(_TaskBase):
         self._cfg.closed_loop_force = int(on)
         self._sync_cfg()
 
+    def enablePassivity(self):
+        self._cfg.passivity_enabled = 1
+        self._sync_cfg()
+
+    def disablePassivity(self):
+        self._cfg.passivity_enabled = 0
+        self._sync_cfg()
+
     def setClosedLoopMomentControl(self, on=True):
         self._cfg.closed_loop_moment = int(on)
         self._sync_cfg()
