@@ -208,7 +208,8 @@ struct Frames {
 	real R[N][9];
 	real p[N][3];
 };
-DI void fk(const DevModel& md, const real* q, Frames& F) {
+template <class MD>
+DI void fk(const MD& md, const real* q, Frames& F) {
 	real Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pp[3] = {0, 0, 0};
 	UNROLL for (int i = 0; i < N; i++) {
 		real RE[9];
@@ -261,7 +262,8 @@ DI void jacobian(const DevTask& t, const Frames& F, const real* x, real* J) {
 }
 // Joint-space inertia matrix by the composite-rigid-body algorithm with spatial inertias expressed
 // about the world origin (what Sai2Model::updateModel() obtains from RBDL's CRBA).
-DI void mass_matrix(const DevModel& md, const Frames& F, real* M) {
+template <class MD>
+DI void mass_matrix(const MD& md, const Frames& F, real* M) {
 	real z[N][3], v[N][3];	// joint twists (z_i, p_i x z_i)
 	UNROLL for (int i = 0; i < N; i++) {
 		z[i][0] = F.R[i][2];
@@ -304,7 +306,8 @@ DI void mass_matrix(const DevModel& md, const Frames& F, real* M) {
 	}
 }
 // Sai2Model::jointGravityVector (RobotController.cpp:71): g_i = -sum_k m_k (z_i x (c_k - p_i)) . gravity
-DI void gravity_vector(const DevModel& md, const Frames& F, real* g) {
+template <class MD>
+DI void gravity_vector(const MD& md, const Frames& F, real* g) {
 	real mt = 0, h[3] = {0, 0, 0};
 	UNROLL for (int k = N - 1; k >= 0; k--) {
 		const real* R = F.R[k];

@@ -8,6 +8,7 @@
 
 #include "sai2b_device.hpp"
 #include "sai2b_fast.hpp"
+#include "sai2b_baked_panda.h"
 #include "sai2b_launch.h"
 
 namespace sai2b {
@@ -84,7 +85,10 @@ __global__ __launch_bounds__(64) void tick_kernel(const DevParams* __restrict__ 
 // sai2b_fast.hpp. A wavefront runs it only when all of its robots are certified non-singular (and
 // none is leaving a singular region); otherwise it touches no state, raises its flag in wave_flags
 // and the flag-gated generic kernel launched right behind handles that wavefront.
-template <int FAST>
+// BAKED selects where the robot constants come from: false = the ctx's parameter block (any robot),
+// true = the compile-time Panda literals of sai2b_baked_panda.h (chosen by the host only when the ctx
+// model is bit-equal to them): no scalar loads from the parameter block for the model phase.
+template <int FAST, bool BAKED>
 __global__ __launch_bounds__(64) void tick_fast_kernel(const DevParams* __restrict__ Pp, int with_comp,
 														  int* __restrict__ wave_flags) {
 	const DevParams& P = *Pp;
@@ -109,16 +113,26 @@ __global__ __launch_bounds__(64) void tick_fast_kernel(const DevParams* __restri
 	real J[6 * N], M[N * N], g[N], Fu[6], Ff[6];
 	{
 		Frames F;
-		fk(P.model, rc.q, F);
+		if constexpr (BAKED)
+			fk(PandaBaked{}, rc.q, F);
+		else
+			fk(P.model, rc.q, F);
 		real x[3], R[9];
 		frame_pose(t0, F, x, R);
 		jacobian(t0, F, x, J);
 		SAI2B_PHASE();
 		mft_law(t0, rc, J, x, R, in0, Fu, Ff);	// MotionForceTask.cpp:278-503 (integrators not yet stored)
 		SAI2B_PHASE();
-		mass_matrix(P.model, F, M);
-		if (P.gravity_comp)
-			gravity_vector(P.model, F, g);
+		if constexpr (BAKED)
+			mass_matrix(PandaBaked{}, F, M);
+		else
+			mass_matrix(P.model, F, M);
+		if (P.gravity_comp) {
+			if constexpr (BAKED)
+				gravity_vector(PandaBaked{}, F, g);
+			else
+				gravity_vector(P.model, F, g);
+		}
 		else {
 			UNROLL for (int i = 0; i < N; i++) g[i] = 0;
 		}
@@ -184,17 +198,26 @@ __global__ __launch_bounds__(64) void reinit_kernel(const DevParams* __restrict_
 
 }  // namespace sai2b
 
-extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int debug, int fast, int commit_sh,
+static void launch_fast(int fast, int baked, dim3 grid, dim3 block, hipStream_t stream, const sai2b::DevParams* d_params,
+						int with_comp, int* wave_flags) {
+	if (fast == 2 && baked)
+		hipLaunchKernelGGL((sai2b::tick_fast_kernel<2, true>), grid, block, 0, stream, d_params, with_comp, wave_flags);
+	else if (fast == 2)
+		hipLaunchKernelGGL((sai2b::tick_fast_kernel<2, false>), grid, block, 0, stream, d_params, with_comp, wave_flags);
+	else if (baked)
+		hipLaunchKernelGGL((sai2b::tick_fast_kernel<1, true>), grid, block, 0, stream, d_params, with_comp, wave_flags);
+	else
+		hipLaunchKernelGGL((sai2b::tick_fast_kernel<1, false>), grid, block, 0, stream, d_params, with_comp, wave_flags);
+}
+
+extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int commit_sh,
 								 int with_comp, int do_torque, int* wave_flags, hipStream_t stream) {
 	const dim3 grid((B + 63) / 64), block(64);
 	// the fast path produces torques only: introspection and model-only passes use the generic kernel
 	if (debug) {
 		hipLaunchKernelGGL((sai2b::tick_kernel<true>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, nullptr);
 	} else if (fast != 0 && do_torque && commit_sh) {
-		if (fast == 2)
-			hipLaunchKernelGGL((sai2b::tick_fast_kernel<2>), grid, block, 0, stream, d_params, with_comp, wave_flags);
-		else
-			hipLaunchKernelGGL((sai2b::tick_fast_kernel<1>), grid, block, 0, stream, d_params, with_comp, wave_flags);
+		launch_fast(fast, baked, grid, block, stream, d_params, with_comp, wave_flags);
 		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, wave_flags);
 	} else {
 		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, nullptr);
@@ -202,7 +225,8 @@ extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int de
 	return (int)hipGetLastError();
 }
 
-extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, int debug, int fast, int part, int* wave_flags,
+extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int part,
+									  int* wave_flags,
 									  hipStream_t stream) {
 	const dim3 grid((B + 63) / 64), block(64);
 	if (debug)
@@ -211,10 +235,8 @@ extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, i
 		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, 1, 1, 1, nullptr);
 	else if (part == 1)
 		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, 1, 1, 1, wave_flags);
-	else if (fast == 2)
-		hipLaunchKernelGGL((sai2b::tick_fast_kernel<2>), grid, block, 0, stream, d_params, 1, wave_flags);
 	else
-		hipLaunchKernelGGL((sai2b::tick_fast_kernel<1>), grid, block, 0, stream, d_params, 1, wave_flags);
+		launch_fast(fast, baked, grid, block, stream, d_params, 1, wave_flags);
 	return (int)hipGetLastError();
 }
 

@@ -4,10 +4,11 @@
 
 #include "sai2b_params.h"
 
-extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int debug, int fast, int commit_sh,
+extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int commit_sh,
 								 int with_comp, int do_torque, int* wave_flags, hipStream_t stream);
 extern "C" int sai2b_launch_reinit(const sai2b::DevParams* d_params, int B, hipStream_t stream);
 // one kernel of a (fast) tick on its own, for per-kernel timing: part 0 = first kernel, part 1 = the
 // flag-gated generic kernel behind the SVD-free one
-extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, int debug, int fast, int part, int* wave_flags,
+extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int part,
+									  int* wave_flags,
 									  hipStream_t stream);

@@ -443,3 +443,30 @@ def test_long_run_history_wraps_and_integrators_follow_oracle():
         assert e.max() < 1e-5, (t, e.max())
     assert sing_ticks > 2000, "the run should spend many robot-ticks in the singular branches"
     assert (c1 + c2).max() == 200, "history ring must have wrapped (cap 200)"
+
+
+def test_modified_robot_model_runtime_constants():
+    """a 7-DOF arm that is NOT the built-in Panda (other link lengths, masses, a general inertia
+    tensor, a tilted joint axis): the kernels read the model from the ctx parameter block instead of the
+    compile-time Panda constants; SVD-free and generic kernels against the oracle"""
+    B = 512
+    inp = pkg.workloads.make_inputs(3, B=B, seed=88)
+    mo, mg = ol.panda_model(), pkg.panda_model()
+    for m in (mo, mg):
+        m.joint_xyz[2][1] = -0.29
+        m.joint_xyz[4][1] = 0.41
+        m.joint_rpy[3][1] = 0.2
+        m.link_mass[1] = 4.2
+        m.link_com[5][2] = 0.03
+        for k, v in enumerate((0.12, 0.08, 0.1, 0.01, -0.02, 0.015)):
+            m.link_inertia[4][k] = v
+    for introspection in (False, True):
+        o = ol.Oracle(mo, ol.task_configs(inp["tasks"]), B, threads=8)
+        g = pkg.Controller(mg, pkg.task_configs(inp["tasks"]), B, introspection=introspection)
+        ol.load_inputs(o, inp)
+        ol.load_inputs(g, inp)
+        tau_o, tau_g = o.tick(), g.tick()
+        _, _, ro = o.get_mft_singularity(0)
+        e = _err(tau_g, tau_o)
+        assert e[ro == 6].max() < 10 * TOL, e[ro == 6].max()
+        assert e.max() < 1e-6
