@@ -115,6 +115,15 @@ typedef struct sai2b_task_config {
 	int sh_buffer_size;
 	double kp_type_1, kv_type_1, kv_type_2;
 	int enforce_type_1_strategy, enforce_handling_strategy;
+
+	/* ---- internal online trajectory generation (JointTask.h:38-42,294-324;
+	 * MotionForceTask.h:67-74,387-427): on by default, acceleration-limited. The desired state fed
+	 * to the control law is the OTG's next state instead of the goal. ---- */
+	int use_internal_otg;		   /* enableInternalOtgAccelerationLimited / disableInternalOtg */
+	int internal_otg_jerk_limited; /* must be 0: the jerk-limited generator is not implemented */
+	double otg_max_velocity[SAI2B_DOF], otg_max_acceleration[SAI2B_DOF]; /* JointTask, per task dof */
+	double otg_max_linear_velocity, otg_max_linear_acceleration;		 /* MotionForceTask */
+	double otg_max_angular_velocity, otg_max_angular_acceleration;
 } sai2b_task_config;
 
 typedef struct sai2b_ctx sai2b_ctx;

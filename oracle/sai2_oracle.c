@@ -7,6 +7,7 @@
  * restated in plain C. Every block cites the reference lines it follows.
  */
 #include "sai2_oracle.h"
+#include "otg_oracle.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -407,8 +408,12 @@ int oracle_default_joint_task(sai2b_task_config* c, const char* name, int task_d
 		c->kv[i] = 14.0;
 		c->ki[i] = 0.0;
 		c->saturation_velocity[i] = M_PI / 3.0;
+		c->otg_max_velocity[i] = M_PI / 3.0;	 /* JointTask.h:40 */
+		c->otg_max_acceleration[i] = 2.0 * M_PI; /* JointTask.h:41 */
 	}
 	c->use_velocity_saturation = 0;
+	c->use_internal_otg = 1; /* JointTask.h:38-39 */
+	c->internal_otg_jerk_limited = 0;
 	return 0;
 }
 
@@ -499,6 +504,12 @@ int oracle_default_motion_force_task(sai2b_task_config* c, const char* name, int
 	c->angular_saturation_velocity = M_PI / 3;
 	eye(3, c->sensor_rot); /* MotionForceTask.cpp:94 */
 	sh_defaults(c);
+	c->use_internal_otg = 1; /* MotionForceTask.h:67-72 */
+	c->internal_otg_jerk_limited = 0;
+	c->otg_max_linear_velocity = 0.3;
+	c->otg_max_linear_acceleration = 2.0;
+	c->otg_max_angular_velocity = M_PI / 3;
+	c->otg_max_angular_acceleration = 2.0 * M_PI;
 	return 0;
 }
 
@@ -518,6 +529,8 @@ typedef struct {
 	int k; /* columns of the range basis, 0 = "zero range" */
 	/* goals / state */
 	double goal_q[N7], goal_dq[N7], goal_ddq[N7], integ[N7];
+	double cur_pos[N7];						/* _current_position (JointTask.cpp:299) */
+	double des_q[N7], des_dq[N7], des_ddq[N7]; /* _desired_* (JointTask.cpp:308-320) */
 	double tau[N7];
 } jt_t;
 
@@ -545,6 +558,9 @@ typedef struct {
 	double popc_po, popc_ecorr, popc_vsum, popc_Rc;
 	int popc_counter, popc_head, popc_size;
 	double popc_ring[POPC_RING];
+	double cur_pos[3], cur_rot[9]; /* _current_position/_orientation (MotionForceTask.cpp:286-289) */
+	/* _desired_* (MotionForceTask.cpp:386-407) */
+	double des_pos[3], des_rot[9], des_v[3], des_w[3], des_a[3], des_al[3];
 } mft_t;
 
 struct oracle_ctx {
@@ -555,6 +571,10 @@ struct oracle_ctx {
 	robot_t* robots;
 	jt_t* jt[SAI2B_MAX_TASKS];
 	mft_t* mft[SAI2B_MAX_TASKS];
+	/* internal OTG objects: they exist (and are re-initialised) whether or not the OTG is enabled,
+	 * as in the reference (JointTask.cpp:71,106; MotionForceTask.cpp:171,244) */
+	otg_joints* jotg[SAI2B_MAX_TASKS];
+	otg_cartesian* cotg[SAI2B_MAX_TASKS];
 };
 
 /* ---- model (the subset of sai2-model the path calls) ---- */
@@ -661,9 +681,28 @@ static void lambda_of(int m, const double* J, const double* Minv, double* L) {
 }
 
 /* ---- JointTask ---- */
-static void jt_reinit(const sai2b_task_config* t, const robot_t* r, jt_t* s) { /* JointTask.cpp:91-107 */
+static void jt_reinit(const sai2b_task_config* t, const robot_t* r, jt_t* s, otg_joints* o) {
+	/* JointTask.cpp:91-107 */
 	mm(t->task_dof, N7, 1, t->joint_selection, r->q, s->goal_q);
 	for (int i = 0; i < N7; i++) s->goal_dq[i] = s->goal_ddq[i] = s->integ[i] = 0;
+	for (int i = 0; i < t->task_dof; i++) {
+		s->cur_pos[i] = s->des_q[i] = s->goal_q[i];
+		s->des_dq[i] = s->des_ddq[i] = 0;
+	}
+	otg_joints_reinitialize(o, s->cur_pos);
+}
+/* JointTask::enableInternalOtgAccelerationLimited (JointTask.cpp:360-381) */
+static void jt_otg_enable(const sai2b_task_config* t, const jt_t* s, otg_joints* o, int was_enabled) {
+	if (!was_enabled) otg_joints_reinitialize(o, s->cur_pos);
+	otg_joints_set_limits(o, t->otg_max_velocity, t->otg_max_acceleration);
+	otg_joints_disable_jerk_limits(o);
+}
+/* JointTask::initialSetup, OTG part + reInitializeTask (JointTask.cpp:50,70-89) */
+static void jt_construct(const sai2b_task_config* t, const robot_t* r, jt_t* s, otg_joints* o) {
+	mm(t->task_dof, N7, 1, t->joint_selection, r->q, s->cur_pos);
+	otg_joints_init(o, t->task_dof, s->cur_pos, t->loop_timestep);
+	if (t->use_internal_otg) jt_otg_enable(t, s, o, 0);
+	jt_reinit(t, r, s, o);
 }
 static void jt_update(const sai2b_task_config* t, const robot_t* r, jt_t* s, const double* N_prec) {
 	/* JointTask.cpp:218-283 */
@@ -692,7 +731,7 @@ static void jt_update(const sai2b_task_config* t, const robot_t* r, jt_t* s, con
 			eye(s->k, s->M_partial_mod);
 	}
 }
-static void jt_torques(const sai2b_task_config* t, const robot_t* r, jt_t* s, double* tau) {
+static void jt_torques(const sai2b_task_config* t, const robot_t* r, jt_t* s, otg_joints* o, double* tau) {
 	/* JointTask.cpp:294-356 */
 	int k0 = t->task_dof, k = s->k;
 	double cur[N7], vel[N7], f[N7];
@@ -700,10 +739,25 @@ static void jt_torques(const sai2b_task_config* t, const robot_t* r, jt_t* s, do
 	mm(k0, N7, N7, t->joint_selection, s->N_prec, s->Jp);
 	mm(k0, N7, 1, t->joint_selection, r->q, cur);
 	mm(k0, N7, 1, t->joint_selection, r->dq, vel);
+	memcpy(s->cur_pos, cur, sizeof(double) * k0);
 	if (k == 0) return;
-	const double *des_q = s->goal_q, *des_ddq = s->goal_ddq;
+	for (int i = 0; i < k0; i++) {
+		s->des_q[i] = s->goal_q[i];
+		s->des_dq[i] = s->goal_dq[i];
+		s->des_ddq[i] = s->goal_ddq[i];
+	}
+	if (t->use_internal_otg) { /* :313-320 */
+		otg_joints_set_goal(o, s->goal_q, s->goal_dq);
+		otg_joints_update(o);
+		for (int i = 0; i < k0; i++) {
+			s->des_q[i] = o->output.np[i];
+			s->des_dq[i] = o->output.nv[i];
+			s->des_ddq[i] = o->output.na[i];
+		}
+	}
+	const double *des_q = s->des_q, *des_ddq = s->des_ddq;
 	double des_dq[N7];
-	for (int i = 0; i < k0; i++) des_dq[i] = s->goal_dq[i];
+	for (int i = 0; i < k0; i++) des_dq[i] = s->des_dq[i];
 	for (int i = 0; i < k0; i++) s->integ[i] += (cur[i] - des_q[i]) * t->loop_timestep;
 	if (t->use_velocity_saturation) { /* :327-340 (loop bound fixed to task dof: SURVEY App. B-7) */
 		for (int i = 0; i < k0; i++) {
@@ -742,14 +796,33 @@ static void jt_compensation(const sai2b_task_config* t, const robot_t* r, const 
 }
 
 /* ---- MotionForceTask + SingularityHandler ---- */
-static void mft_reinit(const sai2b_task_config* t, const robot_t* r, mft_t* s) {
+static void mft_reinit(const sai2b_task_config* t, const robot_t* r, mft_t* s, otg_cartesian* o) {
 	/* MotionForceTask.cpp:204-245; SingularityHandler.cpp:53-63 */
 	frame_pose(t, r->Rl, r->pl, s->g_pos, s->g_rot);
 	for (int i = 0; i < 3; i++) {
 		s->g_v[i] = s->g_w[i] = s->g_a[i] = s->g_al[i] = s->g_f[i] = s->g_m[i] = 0;
 		s->sens_f[i] = s->sens_m[i] = 0;
 		s->integ_pos[i] = s->integ_ori[i] = s->integ_f[i] = s->integ_m[i] = 0;
+		s->des_v[i] = s->des_w[i] = s->des_a[i] = s->des_al[i] = 0;
 	}
+	memcpy(s->cur_pos, s->g_pos, sizeof(s->cur_pos));
+	memcpy(s->cur_rot, s->g_rot, sizeof(s->cur_rot));
+	memcpy(s->des_pos, s->g_pos, sizeof(s->des_pos));
+	memcpy(s->des_rot, s->g_rot, sizeof(s->des_rot));
+	otg_cartesian_reinitialize(o, s->cur_pos, s->cur_rot);
+}
+/* MotionForceTask::enableInternalOtgAccelerationLimited (MotionForceTask.cpp:511-523) */
+static void mft_otg_enable(const sai2b_task_config* t, const mft_t* s, otg_cartesian* o, int was_enabled) {
+	if (!was_enabled) otg_cartesian_reinitialize(o, s->cur_pos, s->cur_rot);
+	otg_cartesian_set_limits(o, t->otg_max_linear_velocity, t->otg_max_linear_acceleration,
+							 t->otg_max_angular_velocity, t->otg_max_angular_acceleration);
+}
+/* MotionForceTask::initialSetup, OTG part + reInitializeTask (MotionForceTask.cpp:100-103,170-201) */
+static void mft_construct(const sai2b_task_config* t, const robot_t* r, mft_t* s, otg_cartesian* o) {
+	frame_pose(t, r->Rl, r->pl, s->cur_pos, s->cur_rot);
+	otg_cartesian_init(o, s->cur_pos, s->cur_rot, t->loop_timestep);
+	if (t->use_internal_otg) mft_otg_enable(t, s, o, 0);
+	mft_reinit(t, r, s, o);
 }
 static void popc_init(mft_t* s) { /* POPCExplicitForceControl.cpp:10-22 */
 	s->popc_po = s->popc_ecorr = s->popc_vsum = 0;
@@ -1057,7 +1130,8 @@ static void sigma_pair(const double* P6, int blk, int dim, const double* axis, c
 static void mv3(const double* A, const double* x, double* y) {
 	for (int i = 0; i < 3; i++) y[i] = A[3 * i] * x[0] + A[3 * i + 1] * x[1] + A[3 * i + 2] * x[2];
 }
-static void mft_torques(const oracle_ctx* c, const sai2b_task_config* t, const robot_t* r, mft_t* s, double* tau) {
+static void mft_torques(const oracle_ctx* c, const sai2b_task_config* t, const robot_t* r, mft_t* s,
+						otg_cartesian* o, double* tau) {
 	/* MotionForceTask.cpp:278-509 */
 	double Jw[42], x[3], R[9], v[3], w[3];
 	for (int i = 0; i < N7; i++) tau[i] = 0;
@@ -1067,6 +1141,8 @@ static void mft_torques(const oracle_ctx* c, const sai2b_task_config* t, const r
 	frame_pose(t, r->Rl, r->pl, x, R);
 	mm(3, N7, 1, s->J, r->dq, v);
 	mm(3, N7, 1, s->J + 21, r->dq, w);
+	memcpy(s->cur_pos, x, sizeof(s->cur_pos));
+	memcpy(s->cur_rot, R, sizeof(s->cur_rot));
 	if (t->pos_range + t->ori_range == 0) return;
 	double sf[9], sp[9], sm[9], so[9];
 	sigma_pair(t->partial_projection, 0, t->force_space_dimension, t->force_axis, R,
@@ -1136,11 +1212,30 @@ static void mft_torques(const oracle_ctx* c, const sai2b_task_config* t, const r
 		for (int i = 0; i < 3; i++) e[i] = -t->kv_moment[i] * w[i];
 		mv3(sm, e, f_moment);
 	}
-	/* linear motion (:385-437); desired = goal (internal OTG is a "next" row) */
+	/* desired state: the goal, or the next OTG state (:385-407) */
+	memcpy(s->des_pos, s->g_pos, sizeof(s->des_pos));
+	memcpy(s->des_rot, s->g_rot, sizeof(s->des_rot));
+	memcpy(s->des_v, s->g_v, sizeof(s->des_v));
+	memcpy(s->des_w, s->g_w, sizeof(s->des_w));
+	memcpy(s->des_a, s->g_a, sizeof(s->des_a));
+	memcpy(s->des_al, s->g_al, sizeof(s->des_al));
+	if (t->use_internal_otg) {
+		otg_cartesian_set_goal_position(o, s->g_pos, s->g_v);
+		otg_cartesian_set_goal_orientation(o, s->g_rot, s->g_w);
+		otg_cartesian_update(o);
+		for (int i = 0; i < 3; i++) {
+			s->des_pos[i] = o->output.np[i];
+			s->des_v[i] = o->output.nv[i];
+			s->des_a[i] = o->output.na[i];
+		}
+		otg_cartesian_next_orientation(o, s->des_rot);
+		otg_cartesian_next_angular(o, s->des_w, s->des_al);
+	}
+	/* linear motion (:409-437) */
 	double des_v[3], des_w[3];
-	memcpy(des_v, s->g_v, sizeof(des_v));
-	memcpy(des_w, s->g_w, sizeof(des_w));
-	for (int i = 0; i < 3; i++) e[i] = x[i] - s->g_pos[i];
+	memcpy(des_v, s->des_v, sizeof(des_v));
+	memcpy(des_w, s->des_w, sizeof(des_w));
+	for (int i = 0; i < 3; i++) e[i] = x[i] - s->des_pos[i];
 	mv3(sp, e, y);
 	for (int i = 0; i < 3; i++) s->integ_pos[i] += y[i] * dt;
 	if (t->use_velocity_saturation) {
@@ -1151,16 +1246,16 @@ static void mft_torques(const oracle_ctx* c, const sai2b_task_config* t, const r
 		double n = sqrt(des_v[0] * des_v[0] + des_v[1] * des_v[1] + des_v[2] * des_v[2]);
 		if (n > t->linear_saturation_velocity)
 			for (int i = 0; i < 3; i++) des_v[i] *= t->linear_saturation_velocity / n;
-		for (int i = 0; i < 3; i++) e[i] = s->g_a[i] - t->kv_pos[i] * (v[i] - des_v[i]);
+		for (int i = 0; i < 3; i++) e[i] = s->des_a[i] - t->kv_pos[i] * (v[i] - des_v[i]);
 	} else {
 		for (int i = 0; i < 3; i++)
-			e[i] = s->g_a[i] - t->kp_pos[i] * (x[i] - s->g_pos[i]) - t->kv_pos[i] * (v[i] - des_v[i]) -
+			e[i] = s->des_a[i] - t->kp_pos[i] * (x[i] - s->des_pos[i]) - t->kv_pos[i] * (v[i] - des_v[i]) -
 				   t->ki_pos[i] * s->integ_pos[i];
 	}
 	mv3(sp, e, f_pos);
 	/* angular motion (:439-468) */
 	double oe[3], step[3];
-	orientation_error(s->g_rot, R, oe);
+	orientation_error(s->des_rot, R, oe);
 	mv3(so, oe, step);
 	for (int i = 0; i < 3; i++) s->integ_ori[i] += step[i] * dt;
 	if (t->use_velocity_saturation) {
@@ -1171,10 +1266,10 @@ static void mft_torques(const oracle_ctx* c, const sai2b_task_config* t, const r
 		double n = sqrt(des_w[0] * des_w[0] + des_w[1] * des_w[1] + des_w[2] * des_w[2]);
 		if (n > t->angular_saturation_velocity)
 			for (int i = 0; i < 3; i++) des_w[i] *= t->angular_saturation_velocity / n;
-		for (int i = 0; i < 3; i++) e[i] = s->g_al[i] - t->kv_ori[i] * (w[i] - des_w[i]);
+		for (int i = 0; i < 3; i++) e[i] = s->des_al[i] - t->kv_ori[i] * (w[i] - des_w[i]);
 	} else {
 		for (int i = 0; i < 3; i++)
-			e[i] = s->g_al[i] - t->kp_ori[i] * step[i] - t->kv_ori[i] * (w[i] - des_w[i]) -
+			e[i] = s->des_al[i] - t->kp_ori[i] * step[i] - t->kv_ori[i] * (w[i] - des_w[i]) -
 				   t->ki_ori[i] * s->integ_ori[i];
 	}
 	mv3(so, e, f_ori);
@@ -1235,21 +1330,24 @@ oracle_ctx* oracle_create(const sai2b_robot_model* model, const sai2b_task_confi
 	c->robots = (robot_t*)calloc(batch, sizeof(robot_t));
 	for (int i = 0; i < n_tasks; i++) {
 		c->cfg[i] = tasks[i];
-		if (tasks[i].type == SAI2B_JOINT_TASK)
+		if (tasks[i].type == SAI2B_JOINT_TASK) {
 			c->jt[i] = (jt_t*)calloc(batch, sizeof(jt_t));
-		else
+			c->jotg[i] = (otg_joints*)calloc(batch, sizeof(otg_joints));
+		} else {
 			c->mft[i] = (mft_t*)calloc(batch, sizeof(mft_t));
+			c->cotg[i] = (otg_cartesian*)calloc(batch, sizeof(otg_cartesian));
+		}
 	}
 	/* the reference constructs tasks from the model's current state; here q = 0 until set */
 	for (int b = 0; b < batch; b++) {
 		update_model(c, &c->robots[b]);
 		for (int i = 0; i < n_tasks; i++) {
 			if (c->jt[i]) {
-				jt_reinit(&c->cfg[i], &c->robots[b], &c->jt[i][b]);
+				jt_construct(&c->cfg[i], &c->robots[b], &c->jt[i][b], &c->jotg[i][b]);
 				eye(N7, c->jt[i][b].N_prec);
 				c->jt[i][b].k = 0;
 			} else {
-				mft_reinit(&c->cfg[i], &c->robots[b], &c->mft[i][b]);
+				mft_construct(&c->cfg[i], &c->robots[b], &c->mft[i][b], &c->cotg[i][b]);
 				sh_init(c, &c->mft[i][b]);
 				popc_init(&c->mft[i][b]);
 				eye(N7, c->mft[i][b].N_prec);
@@ -1263,6 +1361,8 @@ void oracle_destroy(oracle_ctx* c) {
 	for (int i = 0; i < SAI2B_MAX_TASKS; i++) {
 		free(c->jt[i]);
 		free(c->mft[i]);
+		free(c->jotg[i]);
+		free(c->cotg[i]);
 	}
 	free(c->robots);
 	free(c);
@@ -1274,6 +1374,27 @@ int oracle_update_task_config(oracle_ctx* c, int task, const sai2b_task_config* 
 		return fail("update_task_config: bad arguments");
 	if (c->mft[task] && (cfg->passivity_enabled != 0) != (c->cfg[task].passivity_enabled != 0))
 		for (int b = 0; b < c->B; b++) popc_init(&c->mft[task][b]); /* enable()/disable() */
+	if (cfg->internal_otg_jerk_limited) return fail("update_task_config: jerk-limited OTG is not restated");
+	/* enableInternalOtgAccelerationLimited() is applied when the OTG fields change */
+	const sai2b_task_config* old = &c->cfg[task];
+	int otg_changed = (cfg->use_internal_otg != 0) != (old->use_internal_otg != 0);
+	if (c->jt[task]) {
+		for (int i = 0; i < cfg->task_dof; i++)
+			otg_changed |= cfg->otg_max_velocity[i] != old->otg_max_velocity[i] ||
+						   cfg->otg_max_acceleration[i] != old->otg_max_acceleration[i];
+	} else {
+		otg_changed |= cfg->otg_max_linear_velocity != old->otg_max_linear_velocity ||
+					   cfg->otg_max_linear_acceleration != old->otg_max_linear_acceleration ||
+					   cfg->otg_max_angular_velocity != old->otg_max_angular_velocity ||
+					   cfg->otg_max_angular_acceleration != old->otg_max_angular_acceleration;
+	}
+	if (cfg->use_internal_otg && otg_changed)
+		for (int b = 0; b < c->B; b++) {
+			if (c->jt[task])
+				jt_otg_enable(cfg, &c->jt[task][b], &c->jotg[task][b], old->use_internal_otg != 0);
+			else
+				mft_otg_enable(cfg, &c->mft[task][b], &c->cotg[task][b], old->use_internal_otg != 0);
+		}
 	c->cfg[task] = *cfg;
 	return 0;
 }
@@ -1326,9 +1447,9 @@ int oracle_reinitialize(oracle_ctx* c) {
 		ensure_model(c, b);
 		for (int i = 0; i < c->T; i++) {
 			if (c->jt[i])
-				jt_reinit(&c->cfg[i], &c->robots[b], &c->jt[i][b]);
+				jt_reinit(&c->cfg[i], &c->robots[b], &c->jt[i][b], &c->jotg[i][b]);
 			else {
-				mft_reinit(&c->cfg[i], &c->robots[b], &c->mft[i][b]);
+				mft_reinit(&c->cfg[i], &c->robots[b], &c->mft[i][b], &c->cotg[i][b]);
 				sh_init(c, &c->mft[i][b]);
 			}
 		}
@@ -1362,7 +1483,7 @@ static void robot_torques(oracle_ctx* c, int b, double* tau, int with_comp) {
 	for (int i = 0; i < c->T; i++) {
 		double tt[N7], comp[N7];
 		if (c->jt[i]) {
-			jt_torques(&c->cfg[i], r, &c->jt[i][b], tt);
+			jt_torques(&c->cfg[i], r, &c->jt[i][b], &c->jotg[i][b], tt);
 			if (with_comp) {
 				jt_compensation(&c->cfg[i], r, &c->jt[i][b], tau, comp);
 				for (int k = 0; k < N7; k++) tt[k] -= comp[k];
@@ -1371,7 +1492,7 @@ static void robot_torques(oracle_ctx* c, int b, double* tau, int with_comp) {
 		} else {
 			/* MotionForceTask.cpp:270-276: the compensation term multiplies the never-assigned zero
 			 * _Lambda => identically zero */
-			mft_torques(c, &c->cfg[i], r, &c->mft[i][b], tt);
+			mft_torques(c, &c->cfg[i], r, &c->mft[i][b], &c->cotg[i][b], tt);
 			memcpy(c->mft[i][b].tau, tt, sizeof(tt));
 		}
 		for (int k = 0; k < N7; k++) tau[k] += tt[k];
@@ -1505,6 +1626,48 @@ int oracle_get_mft_task_forces(oracle_ctx* c, int task, double* Fu, double* Ff) 
 			if (Fu) Fu[i * c->B + b] = c->mft[task][b].Fu[i];
 			if (Ff) Ff[i * c->B + b] = c->mft[task][b].Ff[i];
 		}
+	return 0;
+}
+int oracle_get_jt_desired(oracle_ctx* c, int task, double* q, double* dq, double* ddq) {
+	if (task < 0 || task >= c->T || !c->jt[task]) return fail("not a JointTask");
+	const int k0 = c->cfg[task].task_dof;
+	for (int b = 0; b < c->B; b++)
+		for (int i = 0; i < k0; i++) {
+			if (q) q[i * c->B + b] = c->jt[task][b].des_q[i];
+			if (dq) dq[i * c->B + b] = c->jt[task][b].des_dq[i];
+			if (ddq) ddq[i * c->B + b] = c->jt[task][b].des_ddq[i];
+		}
+	return 0;
+}
+int oracle_get_mft_desired(oracle_ctx* c, int task, double* pos, double* rot, double* v, double* w, double* a,
+						   double* al) {
+	if (task < 0 || task >= c->T || !c->mft[task]) return fail("not a MotionForceTask");
+	for (int b = 0; b < c->B; b++) {
+		const mft_t* s = &c->mft[task][b];
+		for (int i = 0; i < 3; i++) {
+			if (pos) pos[i * c->B + b] = s->des_pos[i];
+			if (v) v[i * c->B + b] = s->des_v[i];
+			if (w) w[i * c->B + b] = s->des_w[i];
+			if (a) a[i * c->B + b] = s->des_a[i];
+			if (al) al[i * c->B + b] = s->des_al[i];
+		}
+		if (rot)
+			for (int i = 0; i < 9; i++) rot[i * c->B + b] = s->des_rot[i];
+	}
+	return 0;
+}
+/* OTG flags per robot: goal reached, last ruckig result (as doubles) */
+int oracle_get_otg_status(oracle_ctx* c, int task, double* goal_reached, double* result) {
+	if (task < 0 || task >= c->T) return fail("bad task");
+	for (int b = 0; b < c->B; b++) {
+		if (c->jt[task]) {
+			goal_reached[b] = c->jotg[task][b].goal_reached;
+			result[b] = c->jotg[task][b].result_value;
+		} else {
+			goal_reached[b] = c->cotg[task][b].goal_reached;
+			result[b] = c->cotg[task][b].result_value;
+		}
+	}
 	return 0;
 }
 int oracle_get_mft_sh_state(oracle_ctx* c, int task, double* first_type, double* c1, double* c2) {

@@ -80,6 +80,13 @@ int oracle_get_mft_lambda(oracle_ctx* ctx, int task, double* Lambda_ns_full,
 						  double* Lambda_ns_mod_full);
 /* MFT: F_unit and F_force of the last computeTorques, [6][B] each */
 int oracle_get_mft_task_forces(oracle_ctx* ctx, int task, double* F_unit, double* F_force);
+/* desired state of the last computeTorques = goal, or the internal OTG's next state
+ * (JointTask.h:182-198 getDesired*, MotionForceTask.h getDesired*); any pointer may be NULL */
+int oracle_get_jt_desired(oracle_ctx* ctx, int task, double* q, double* dq, double* ddq);
+int oracle_get_mft_desired(oracle_ctx* ctx, int task, double* pos, double* rot, double* lin_vel,
+						   double* ang_vel, double* lin_acc, double* ang_acc);
+/* internal OTG flags per robot, as doubles [B]: isGoalReached(), last ruckig Result */
+int oracle_get_otg_status(oracle_ctx* ctx, int task, double* goal_reached, double* result);
 /* MFT singularity classification of the last update: type per robot (0 none, 1 type-1, 2 type-2
  * of the first singular column), type-1 and type-2 counters; as doubles, [B] each */
 int oracle_get_mft_sh_state(oracle_ctx* ctx, int task, double* first_type, double* c1, double* c2);

@@ -107,6 +107,15 @@ class TaskConfig(C.Structure):
         ("kv_type_2", _d),
         ("enforce_type_1_strategy", _i),
         ("enforce_handling_strategy", _i),
+        # internal OTG
+        ("use_internal_otg", _i),
+        ("internal_otg_jerk_limited", _i),
+        ("otg_max_velocity", _d * DOF),
+        ("otg_max_acceleration", _d * DOF),
+        ("otg_max_linear_velocity", _d),
+        ("otg_max_linear_acceleration", _d),
+        ("otg_max_angular_velocity", _d),
+        ("otg_max_angular_acceleration", _d),
     ]
 
 

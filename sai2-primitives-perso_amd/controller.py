@@ -41,8 +41,11 @@ def panda_model():
     return m
 
 
-def joint_task_config(name=None, selection=None):
-    """sai2b_default_joint_task(): JointTask ctor + defaults (JointTask.cpp:14-89)."""
+def joint_task_config(name=None, selection=None, internal_otg=False):
+    """sai2b_default_joint_task(): JointTask ctor + defaults (JointTask.cpp:14-89).
+    The library default is the reference's: internal OTG on (JointTask.h:38). This helper turns it
+    off unless internal_otg=True, the way the reference's examples call disableInternalOtg() after
+    construction (examples/05-...cpp:117) and as BASELINE's workloads are defined."""
     lib = _abi.load_library()
     c = TaskConfig()
     sel = None if selection is None else np.ascontiguousarray(selection, dtype=np.float64)
@@ -50,12 +53,16 @@ def joint_task_config(name=None, selection=None):
         raise ValueError("joint selection matrix size not consistent with robot dof in JointTask constructor\n")
     rc = lib.sai2b_default_joint_task(C.byref(c), name.encode() if name else None, 0 if sel is None else sel.shape[0], _dp(sel))
     _check(lib, None, rc)
+    if not internal_otg:
+        c.use_internal_otg = 0
     return c
 
 
-def motion_force_task_config(name=None, link=EE_LINK, frame_pos=EE_FRAME_POS, frame_rot=None, partial=None):
+def motion_force_task_config(name=None, link=EE_LINK, frame_pos=EE_FRAME_POS, frame_rot=None, partial=None,
+                             internal_otg=False):
     """sai2b_default_motion_force_task(): MotionForceTask ctors + defaults (MotionForceTask.cpp:16-202).
-    partial = (translation directions [n,3], rotation directions [m,3]) selects the partial-task ctor."""
+    partial = (translation directions [n,3], rotation directions [m,3]) selects the partial-task ctor.
+    internal_otg: see joint_task_config (library default on, this helper's default off)."""
     lib = _abi.load_library()
     c = TaskConfig()
     fp = np.ascontiguousarray(frame_pos, dtype=np.float64)
@@ -71,6 +78,8 @@ def motion_force_task_config(name=None, link=EE_LINK, frame_pos=EE_FRAME_POS, fr
         nt, _dp(dt) if nt and nt > 0 else None, nr, _dp(dr) if nr and nr > 0 else None,
     )
     _check(lib, None, rc)
+    if not internal_otg:
+        c.use_internal_otg = 0
     return c
 
 

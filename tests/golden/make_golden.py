@@ -188,7 +188,8 @@ class Robot:
 
 
 class JointTaskNP:
-    """JointTask.cpp:14-356 (OTG disabled)"""
+    """JointTask.cpp:14-356. opt["otg"] = dict(vmax=, amax=) enables the internal OTG (acceleration
+    limited), restated in otg_np.py on top of the reference's own ruckig core."""
 
     def __init__(self, robot, selection=None, **opt):
         self.robot = robot
@@ -205,6 +206,12 @@ class JointTaskNP:
         self.dt = 0.001
         self.N_prec = np.eye(N)
         self.R = None
+        self.otg = None
+        if opt.get("otg") is not None:  # JointTask.cpp:70-86
+            import otg_np
+            self.otg = otg_np.JointOTGNP(self.S @ robot.q, self.dt, opt["otg"].get("lib"))
+            self.otg.set_limits(opt["otg"].get("vmax", np.pi / 3), opt["otg"].get("amax", 2 * np.pi))
+            self.otg.disable_jerk_limits()
         self.reinit()
 
     def reinit(self):
@@ -212,6 +219,9 @@ class JointTaskNP:
         self.goal_dq = np.zeros(self.k0)
         self.goal_ddq = np.zeros(self.k0)
         self.integ = np.zeros(self.k0)
+        self.des_q, self.des_dq, self.des_ddq = self.goal_q.copy(), np.zeros(self.k0), np.zeros(self.k0)
+        if self.otg is not None:
+            self.otg.reinitialize(self.goal_q)
 
     def update(self, N_prec):
         rb = self.robot
@@ -237,6 +247,11 @@ class JointTaskNP:
         if self.R is None:
             return np.zeros(N)
         des_q, des_dq, des_ddq = self.goal_q, self.goal_dq.copy(), self.goal_ddq
+        if self.otg is not None:  # JointTask.cpp:313-320
+            self.otg.set_goal(self.goal_q, self.goal_dq)
+            self.otg.update()
+            des_q, des_dq, des_ddq = self.otg.next()
+        self.des_q, self.des_dq, self.des_ddq = des_q.copy(), des_dq.copy(), des_ddq.copy()
         self.integ = self.integ + (cur - des_q) * self.dt
         if self.vsat is not None:
             kvi = gain_pinv(self.kv)
@@ -259,7 +274,8 @@ class JointTaskNP:
 
 
 class MotionForceTaskNP:
-    """MotionForceTask.cpp:16-509 + SingularityHandler.cpp:24-368 (OTG disabled, POPC disabled)"""
+    """MotionForceTask.cpp:16-509 + SingularityHandler.cpp:24-368. opt["otg"] = dict(lv=, la=, av=, aa=)
+    enables the internal OTG (acceleration limited; otg_np.py)."""
 
     def __init__(self, robot, link=6, frame_pos=(0, 0, 0.22), frame_rot=None, partial=None, **opt):
         self.robot = robot
@@ -312,6 +328,12 @@ class MotionForceTaskNP:
         self.types, self.hist, self.c1, self.c2 = [], [], 0, 0
         self.q_prior, self.dq_prior = 0.5 * (LOWER + UPPER), np.zeros(N)
         self.t2dir = np.ones(N)
+        self.otg = None
+        if opt.get("otg") is not None:  # MotionForceTask.cpp:170-189
+            import otg_np
+            o = opt["otg"]
+            self.otg = otg_np.CartesianOTGNP(*self.pose(), self.dt, o.get("lib"))
+            self.otg.set_limits(o.get("lv", 0.3), o.get("la", 2.0), o.get("av", np.pi / 3), o.get("aa", 2 * np.pi))
         self.reinit()
 
     def pose(self, R=None, p=None):
@@ -324,6 +346,8 @@ class MotionForceTaskNP:
         self.g_v, self.g_w, self.g_a, self.g_al = (np.zeros(3) for _ in range(4))
         self.g_f, self.g_m, self.sens_f, self.sens_m = (np.zeros(3) for _ in range(4))
         self.i_pos, self.i_ori, self.i_f, self.i_m = (np.zeros(3) for _ in range(4))
+        if self.otg is not None:
+            self.otg.reinitialize(self.g_pos, self.g_rot)
 
     def update(self, N_prec):
         rb = self.robot
@@ -477,19 +501,25 @@ class MotionForceTaskNP:
             f_moment = sm @ (fb - self.kv_m * w)
         else:
             f_moment = sm @ (-self.kv_m * w)
-        des_v, des_w = self.g_v.copy(), self.g_w.copy()
-        self.i_pos = self.i_pos + sp @ (x - self.g_pos) * self.dt
+        d_pos, d_rot, des_v, des_w, d_a, d_al = self.g_pos, self.g_rot, self.g_v.copy(), self.g_w.copy(), self.g_a, self.g_al
+        if self.otg is not None:  # MotionForceTask.cpp:394-407
+            self.otg.set_goal_position(self.g_pos, self.g_v)
+            self.otg.set_goal_orientation(self.g_rot, self.g_w)
+            self.otg.update()
+            d_pos, d_rot, des_v, des_w, d_a, d_al = self.otg.next()
+        self.desired = (d_pos.copy(), d_rot.copy(), des_v.copy(), des_w.copy(), d_a.copy(), d_al.copy())
+        self.i_pos = self.i_pos + sp @ (x - d_pos) * self.dt
         if self.vsat is not None:
             kvi = gain_pinv(self.kv_pos)
-            des_v = -self.kp_pos * kvi * (sp @ (x - self.g_pos)) - self.ki_pos * kvi * self.i_pos
+            des_v = -self.kp_pos * kvi * (sp @ (x - d_pos)) - self.ki_pos * kvi * self.i_pos
             n = np.linalg.norm(des_v)
             if n > self.vsat[0]:
                 des_v = des_v * self.vsat[0] / n
-            f_pos = sp @ (self.g_a - self.kv_pos * (v - des_v))
+            f_pos = sp @ (d_a - self.kv_pos * (v - des_v))
         else:
-            f_pos = sp @ (self.g_a - self.kp_pos * (x - self.g_pos) - self.kv_pos * (v - des_v)
+            f_pos = sp @ (d_a - self.kp_pos * (x - d_pos) - self.kv_pos * (v - des_v)
                           - self.ki_pos * self.i_pos)
-        step = so @ orientation_error(self.g_rot, R)
+        step = so @ orientation_error(d_rot, R)
         self.i_ori = self.i_ori + step * self.dt
         if self.vsat is not None:
             kvi = gain_pinv(self.kv_ori)
@@ -497,9 +527,9 @@ class MotionForceTaskNP:
             n = np.linalg.norm(des_w)
             if n > self.vsat[1]:
                 des_w = des_w * self.vsat[1] / n
-            f_ori = so @ (self.g_al - self.kv_ori * (w - des_w))
+            f_ori = so @ (d_al - self.kv_ori * (w - des_w))
         else:
-            f_ori = so @ (self.g_al - self.kp_ori * step - self.kv_ori * (w - des_w) - self.ki_ori * self.i_ori)
+            f_ori = so @ (d_al - self.kp_ori * step - self.kv_ori * (w - des_w) - self.ki_ori * self.i_ori)
         Fu = np.concatenate([f_pos, f_ori])
         ff = np.concatenate([sf @ gf, sm @ gm])
         if self.cl_f:

@@ -23,8 +23,8 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    src = os.path.join(ORACLE_DIR, "sai2_oracle.c")
-    if not os.path.exists(ORACLE_LIB) or os.path.getmtime(ORACLE_LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("sai2_oracle.c", "otg_oracle.c", "otg_oracle.h", "sai2_oracle.h")]
+    if not os.path.exists(ORACLE_LIB) or os.path.getmtime(ORACLE_LIB) < max(os.path.getmtime(f) for f in srcs):
         build_oracle()
     L = C.CDLL(ORACLE_LIB)
     P, vp, d, i = C.POINTER, C.c_void_p, C.c_double, C.c_int
@@ -61,6 +61,9 @@ def lib():
     L.oracle_get_mft_sh_state.argtypes = [vp, i, vp, vp, vp]
     L.oracle_get_mft_task_forces.argtypes = [vp, i, vp, vp]
     L.oracle_get_jt_inertia.argtypes = [vp, i, vp, vp]
+    L.oracle_get_jt_desired.argtypes = [vp, i, vp, vp, vp]
+    L.oracle_get_mft_desired.argtypes = [vp, i] + [vp] * 6
+    L.oracle_get_otg_status.argtypes = [vp, i, vp, vp]
     L.oracle_svd.argtypes = [i, i, vp, vp, vp, vp]
     L.oracle_svd.restype = None
     L.oracle_inverse.argtypes = [i, vp, vp]
@@ -87,7 +90,8 @@ def panda_model():
     return m
 
 
-def joint_task(name=None, selection=None):
+def joint_task(name=None, selection=None, internal_otg=False):
+    """oracle defaults; internal OTG off unless asked (same convention as pkg.joint_task_config)"""
     c = TaskConfig()
     sel = None if selection is None else np.ascontiguousarray(selection, dtype=np.float64)
     rc = lib().oracle_default_joint_task(
@@ -98,11 +102,13 @@ def joint_task(name=None, selection=None):
     )
     if rc:
         raise ValueError(lib().oracle_last_error().decode())
+    if not internal_otg:
+        c.use_internal_otg = 0
     return c
 
 
 def motion_force_task(name=None, link=pkg.workloads.EE_LINK, frame_pos=pkg.workloads.EE_FRAME_POS, frame_rot=None,
-                      partial=None):
+                      partial=None, internal_otg=False):
     c = TaskConfig()
     dp = C.POINTER(C.c_double)
     fp = np.ascontiguousarray(frame_pos, dtype=np.float64)
@@ -126,6 +132,8 @@ def motion_force_task(name=None, link=pkg.workloads.EE_LINK, frame_pos=pkg.workl
     )
     if rc:
         raise ValueError(lib().oracle_last_error().decode())
+    if not internal_otg:
+        c.use_internal_otg = 0
     return c
 
 
@@ -269,6 +277,24 @@ class Oracle:
         k0 = self._k0(task)
         a, b = np.empty((k0 * k0, self.B)), np.empty((k0 * k0, self.B))
         assert self.L.oracle_get_jt_inertia(self.h, task, _ptr(a), _ptr(b)) == 0
+        return a, b
+
+
+    def get_jt_desired(self, task):
+        k0 = self._k0(task)
+        q, dq, ddq = np.empty((k0, self.B)), np.empty((k0, self.B)), np.empty((k0, self.B))
+        assert self.L.oracle_get_jt_desired(self.h, task, _ptr(q), _ptr(dq), _ptr(ddq)) == 0
+        return q, dq, ddq
+
+    def get_mft_desired(self, task):
+        B = self.B
+        out = [np.empty((3, B)), np.empty((9, B)), np.empty((3, B)), np.empty((3, B)), np.empty((3, B)), np.empty((3, B))]
+        assert self.L.oracle_get_mft_desired(self.h, task, *[_ptr(x) for x in out]) == 0
+        return tuple(out)
+
+    def get_otg_status(self, task):
+        a, b = np.empty(self.B), np.empty(self.B)
+        assert self.L.oracle_get_otg_status(self.h, task, _ptr(a), _ptr(b)) == 0
         return a, b
 
 
