@@ -179,11 +179,32 @@ public:
 		_cfg.use_velocity_saturation = 0;
 		syncConfig();
 	}
-	// the internal OTG is a "next" row: desired state == goal state
-	void disableInternalOtg() {}
+	// JointTask.h:294-324 — internal OTG (on by default, acceleration-limited: JointTask.h:38-41)
+	void enableInternalOtgAccelerationLimited(const double max_velocity, const double max_acceleration) {
+		if (max_velocity <= 0)
+			throw std::invalid_argument("max velocity cannot be 0 or negative in any directions in OTG_joints::setMaxVelocity\n");
+		if (max_acceleration <= 0)
+			throw std::invalid_argument("max acceleration cannot be 0 or negative in any directions in OTG_joints::setMaxAcceleration\n");
+		for (int i = 0; i < SAI2B_DOF; i++) _cfg.otg_max_velocity[i] = max_velocity, _cfg.otg_max_acceleration[i] = max_acceleration;
+		_cfg.use_internal_otg = 1, _cfg.internal_otg_jerk_limited = 0;
+		syncConfig();
+	}
+	void enableInternalOtgJerkLimited(const double, const double, const double) {
+		throw std::invalid_argument("the jerk-limited internal OTG (enableInternalOtgJerkLimited) is not implemented in this build");
+	}
+	void disableInternalOtg() {
+		_cfg.use_internal_otg = 0;
+		syncConfig();
+	}
+	bool getInternalOtgEnabled() const { return _cfg.use_internal_otg != 0; }
+	// JointTask.h:182-198: goal, or the OTG's next state; [task_dof][B]
+	inline Batch getDesiredPosition() const;
+	inline Batch getDesiredVelocity() const;
+	inline Batch getDesiredAcceleration() const;
 
 protected:
 	inline void flushGoals() override;
+	inline Batch desired(int which) const;
 	Batch _goal_q, _goal_dq, _goal_ddq;
 };
 
@@ -279,7 +300,33 @@ public:
 		_cfg.use_velocity_saturation = 0;
 		syncConfig();
 	}
-	void disableInternalOtg() {}
+	// MotionForceTask.h:387-427 — internal OTG (on by default, acceleration-limited: MotionForceTask.h:67-72)
+	void enableInternalOtgAccelerationLimited(const double max_linear_velocity, const double max_linear_acceleration,
+											  const double max_angular_velocity, const double max_angular_acceleration) {
+		if (max_linear_velocity <= 0 || max_angular_velocity <= 0)
+			throw std::invalid_argument("max velocity set to 0 or negative value in some directions in OTG_6dof_cartesian::setMaxLinearVelocity\n");
+		if (max_linear_acceleration <= 0 || max_angular_acceleration <= 0)
+			throw std::invalid_argument("max acceleration set to 0 or negative value in some directions in OTG_6dof_cartesian::setMaxLinearAcceleration\n");
+		_cfg.otg_max_linear_velocity = max_linear_velocity, _cfg.otg_max_linear_acceleration = max_linear_acceleration;
+		_cfg.otg_max_angular_velocity = max_angular_velocity, _cfg.otg_max_angular_acceleration = max_angular_acceleration;
+		_cfg.use_internal_otg = 1, _cfg.internal_otg_jerk_limited = 0;
+		syncConfig();
+	}
+	void enableInternalOtgJerkLimited(const double, const double, const double, const double, const double, const double) {
+		throw std::invalid_argument("the jerk-limited internal OTG (enableInternalOtgJerkLimited) is not implemented in this build");
+	}
+	void disableInternalOtg() {
+		_cfg.use_internal_otg = 0;
+		syncConfig();
+	}
+	bool getInternalOtgEnabled() const { return _cfg.use_internal_otg != 0; }
+	// goal, or the OTG's next state: position/velocities/accelerations [3][B], orientation [9][B]
+	inline Batch getDesiredPosition() const;
+	inline Batch getDesiredOrientation() const;
+	inline Batch getDesiredLinearVelocity() const;
+	inline Batch getDesiredAngularVelocity() const;
+	inline Batch getDesiredLinearAcceleration() const;
+	inline Batch getDesiredAngularAcceleration() const;
 	// MotionForceTask.h:669-753 (singularity handling)
 	void setSingularityHandlingBounds(const double s_min, const double s_max) {
 		_cfg.s_min = s_min;
@@ -299,6 +346,7 @@ public:
 
 protected:
 	inline void flushGoals() override;
+	inline Batch desired(int which) const;
 	void set(Batch& dst, const Batch& v, size_t rows, const char* what) {
 		checkRows(v, rows, what);
 		dst = v;
@@ -418,6 +466,31 @@ inline Batch MotionForceTask::getSigmaValues() const {
 	detail::check(_owner->ctx(), sai2b_get_mft_singularity(_owner->ctx(), _index, out.data(), nullptr, nullptr));
 	return out;
 }
+inline Batch JointTask::desired(int which) const {
+	if (!_owner) throw std::invalid_argument("task is not attached to a RobotController");
+	Batch out((size_t)_cfg.task_dof * B());
+	double* p[3] = {nullptr, nullptr, nullptr};
+	p[which] = out.data();
+	detail::check(_owner->ctx(), sai2b_get_jt_desired(_owner->ctx(), _index, p[0], p[1], p[2]));
+	return out;
+}
+inline Batch JointTask::getDesiredPosition() const { return desired(0); }
+inline Batch JointTask::getDesiredVelocity() const { return desired(1); }
+inline Batch JointTask::getDesiredAcceleration() const { return desired(2); }
+inline Batch MotionForceTask::desired(int which) const {
+	if (!_owner) throw std::invalid_argument("task is not attached to a RobotController");
+	Batch out((which == 1 ? 9 : 3) * B());
+	double* p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	p[which] = out.data();
+	detail::check(_owner->ctx(), sai2b_get_mft_desired(_owner->ctx(), _index, p[0], p[1], p[2], p[3], p[4], p[5]));
+	return out;
+}
+inline Batch MotionForceTask::getDesiredPosition() const { return desired(0); }
+inline Batch MotionForceTask::getDesiredOrientation() const { return desired(1); }
+inline Batch MotionForceTask::getDesiredLinearVelocity() const { return desired(2); }
+inline Batch MotionForceTask::getDesiredAngularVelocity() const { return desired(3); }
+inline Batch MotionForceTask::getDesiredLinearAcceleration() const { return desired(4); }
+inline Batch MotionForceTask::getDesiredAngularAcceleration() const { return desired(5); }
 inline void JointTask::flushGoals() {
 	if (!_owner) return;
 	auto p = [](const Batch& b) { return b.empty() ? nullptr : b.data(); };

@@ -249,6 +249,17 @@ int sai2b_get_mft_singularity(sai2b_ctx* ctx, int task, double* sigma, double* a
  * MotionForceTask::getUnitMassForce and the observers of POPCBilateralTeleoperation.cpp:81-92,172-182
  * read (MotionForceTask.cpp:478-487) */
 int sai2b_get_mft_task_forces(sai2b_ctx* ctx, int task, double* F_unit, double* F_force);
+/* Desired state the control law tracked in the last torque computation: the goal, or with the
+ * internal OTG on its next state (JointTask::getDesiredPosition/Velocity/Acceleration,
+ * JointTask.h:182-198; MotionForceTask::getDesired*). Host arrays, SoA [rows][B]; any may be NULL.
+ * No introspection switch needed. */
+int sai2b_get_jt_desired(sai2b_ctx* ctx, int task, double* q, double* dq, double* ddq);
+int sai2b_get_mft_desired(sai2b_ctx* ctx, int task, double* pos, double* rot, double* lin_vel,
+						  double* ang_vel, double* lin_acc, double* ang_acc);
+/* Internal OTG flags per robot as doubles [B]: OTG_joints/OTG_6dof_cartesian::isGoalReached()
+ * (OTG_joints.h:152, OTG_6dof_cartesian.h:229) and the last ruckig Result (0 working, 1 finished,
+ * < 0 error: ruckig/include/ruckig/result.hpp:6-18) */
+int sai2b_get_otg_status(sai2b_ctx* ctx, int task, double* goal_reached, double* result);
 /* Sai2Model::M(): [49][B]; J of MFT `task` (JWorldFrame): [42][B]; position [3][B], rotation [9][B] */
 int sai2b_get_model(sai2b_ctx* ctx, int task, double* M, double* J, double* pos, double* rot);
 

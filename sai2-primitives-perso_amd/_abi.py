@@ -179,6 +179,9 @@ EXPORTS = [
     "sai2b_get_task_torques",
     "sai2b_get_mft_singularity",
     "sai2b_get_mft_task_forces",
+    "sai2b_get_jt_desired",
+    "sai2b_get_mft_desired",
+    "sai2b_get_otg_status",
     "sai2b_get_model",
     "sai2b_profile_tick",
     "sai2b_counters",
@@ -243,6 +246,9 @@ def load_library():
     lib.sai2b_get_task_torques.argtypes = [vp, _i, vp]
     lib.sai2b_get_mft_singularity.argtypes = [vp, _i, vp, vp, vp]
     lib.sai2b_get_mft_task_forces.argtypes = [vp, _i, vp, vp]
+    lib.sai2b_get_jt_desired.argtypes = [vp, _i, vp, vp, vp]
+    lib.sai2b_get_mft_desired.argtypes = [vp, _i, vp, vp, vp, vp, vp, vp]
+    lib.sai2b_get_otg_status.argtypes = [vp, _i, vp, vp]
     lib.sai2b_get_model.argtypes = [vp, _i, vp, vp, vp, vp]
     lib.sai2b_profile_tick.argtypes = [vp, _i, P(_d), P(_d)]
     lib.sai2b_counters.argtypes = [vp, P(C.c_longlong), P(C.c_longlong)]

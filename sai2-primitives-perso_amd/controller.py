@@ -251,6 +251,26 @@ class Controller:
         self._rc(self.lib.sai2b_get_mft_task_forces(self.h, task, C.c_void_p(fu.ctypes.data), C.c_void_p(ff.ctypes.data)))
         return fu, ff
 
+    def get_jt_desired(self, task):
+        """desired q, dq, ddq of a JointTask: the goal, or the internal OTG's next state"""
+        k0 = self.tasks[task].task_dof
+        out = [np.empty((k0, self.B)) for _ in range(3)]
+        self._rc(self.lib.sai2b_get_jt_desired(self.h, task, *[C.c_void_p(x.ctypes.data) for x in out]))
+        return tuple(out)
+
+    def get_mft_desired(self, task):
+        """desired position, orientation, linear/angular velocity, linear/angular acceleration"""
+        B = self.B
+        out = [np.empty((r, B)) for r in (3, 9, 3, 3, 3, 3)]
+        self._rc(self.lib.sai2b_get_mft_desired(self.h, task, *[C.c_void_p(x.ctypes.data) for x in out]))
+        return tuple(out)
+
+    def get_otg_status(self, task):
+        """per robot: isGoalReached() and the last ruckig Result of the task's internal OTG"""
+        a, b = np.empty(self.B), np.empty(self.B)
+        self._rc(self.lib.sai2b_get_otg_status(self.h, task, C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data)))
+        return a, b
+
     def get_model(self, task=-1):
         M = np.empty((DOF * DOF, self.B))
         if task < 0:
@@ -359,7 +379,7 @@ class JointTask(_TaskBase):
     """reference src/tasks/JointTask.h:56-75 (ctors), :137-179 (goals), :234-259 (gains)"""
 
     def __init__(self, robot, joint_selection_matrix=None, task_name="joint_task", loop_timestep=0.001):
-        cfg = joint_task_config(task_name, joint_selection_matrix)
+        cfg = joint_task_config(task_name, joint_selection_matrix, internal_otg=True)  # JointTask.h:38
         cfg.loop_timestep = loop_timestep
         super().__init__(robot, cfg)
 
@@ -396,8 +416,41 @@ class JointTask(_TaskBase):
         self._cfg.use_velocity_saturation = 0
         self._sync_cfg()
 
+    def enableInternalOtgAccelerationLimited(self, max_velocity, max_acceleration):
+        """JointTask.cpp:360-381 (scalars or per-task-dof vectors)"""
+        k0 = self._cfg.task_dof
+        v, a = (np.broadcast_to(np.asarray(x, dtype=float), (k0,)) for x in (max_velocity, max_acceleration))
+        if v.min() <= 0:
+            raise ValueError("max velocity cannot be 0 or negative in any directions in OTG_joints::setMaxVelocity\n")
+        if a.min() <= 0:
+            raise ValueError("max acceleration cannot be 0 or negative in any directions in OTG_joints::setMaxAcceleration\n")
+        for i in range(k0):
+            self._cfg.otg_max_velocity[i], self._cfg.otg_max_acceleration[i] = v[i], a[i]
+        self._cfg.use_internal_otg, self._cfg.internal_otg_jerk_limited = 1, 0
+        self._sync_cfg()
+
+    def enableInternalOtgJerkLimited(self, max_velocity, max_acceleration, max_jerk):
+        raise ValueError("the jerk-limited internal OTG (enableInternalOtgJerkLimited) is not implemented in this build")
+
     def disableInternalOtg(self):
-        """the internal OTG is not part of this path: desired state = goal state"""
+        """JointTask.h:320: desired state = goal state"""
+        self._cfg.use_internal_otg = 0
+        self._sync_cfg()
+
+    def getInternalOtgEnabled(self):
+        return bool(self._cfg.use_internal_otg)
+
+    def getDesiredPosition(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_jt_desired(idx)[0]
+
+    def getDesiredVelocity(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_jt_desired(idx)[1]
+
+    def getDesiredAcceleration(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_jt_desired(idx)[2]
 
     def _flush(self):
         if self._owner and self._pending:
@@ -419,7 +472,8 @@ class MotionForceTask(_TaskBase):
                 np.zeros((0, 3)) if controlled_directions_translation is None else controlled_directions_translation,
                 np.zeros((0, 3)) if controlled_directions_rotation is None else controlled_directions_rotation,
             )
-        cfg = motion_force_task_config(task_name, link, compliant_frame_pos, compliant_frame_rot, partial)
+        cfg = motion_force_task_config(task_name, link, compliant_frame_pos, compliant_frame_rot, partial,
+                                       internal_otg=True)  # MotionForceTask.h:67
         cfg.parametrization_in_compliant_frame = int(is_force_motion_parametrization_in_compliant_frame)
         cfg.loop_timestep = loop_timestep
         super().__init__(robot, cfg)
@@ -526,8 +580,53 @@ class MotionForceTask(_TaskBase):
         self._cfg.use_velocity_saturation = 0
         self._sync_cfg()
 
+    def enableInternalOtgAccelerationLimited(self, max_linear_velocity, max_linear_acceleration, max_angular_velocity,
+                                             max_angular_acceleration):
+        """MotionForceTask.cpp:511-523"""
+        c = self._cfg
+        if min(max_linear_velocity, max_angular_velocity) <= 0:
+            raise ValueError("max velocity set to 0 or negative value in some directions in OTG_6dof_cartesian::setMaxLinearVelocity\n")
+        if min(max_linear_acceleration, max_angular_acceleration) <= 0:
+            raise ValueError("max acceleration set to 0 or negative value in some directions in OTG_6dof_cartesian::setMaxLinearAcceleration\n")
+        c.otg_max_linear_velocity, c.otg_max_linear_acceleration = float(max_linear_velocity), float(max_linear_acceleration)
+        c.otg_max_angular_velocity, c.otg_max_angular_acceleration = float(max_angular_velocity), float(max_angular_acceleration)
+        c.use_internal_otg, c.internal_otg_jerk_limited = 1, 0
+        self._sync_cfg()
+
+    def enableInternalOtgJerkLimited(self, *args):
+        raise ValueError("the jerk-limited internal OTG (enableInternalOtgJerkLimited) is not implemented in this build")
+
     def disableInternalOtg(self):
-        """the internal OTG is not part of this path: desired state = goal state"""
+        """MotionForceTask.h:423: desired state = goal state"""
+        self._cfg.use_internal_otg = 0
+        self._sync_cfg()
+
+    def getInternalOtgEnabled(self):
+        return bool(self._cfg.use_internal_otg)
+
+    def getDesiredPosition(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_desired(idx)[0]
+
+    def getDesiredOrientation(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_desired(idx)[1]
+
+    def getDesiredLinearVelocity(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_desired(idx)[2]
+
+    def getDesiredAngularVelocity(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_desired(idx)[3]
+
+    def getDesiredLinearAcceleration(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_desired(idx)[4]
+
+    def getDesiredAngularAcceleration(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_desired(idx)[5]
 
     def setSingularityHandlingBounds(self, s_min, s_max):
         self._cfg.s_min, self._cfg.s_max = float(s_min), float(s_max)

@@ -370,7 +370,7 @@ struct MftIn {
 	real integ[12];	 // pos 3, ori 3, force 3, moment 3
 };
 DI void mft_load(const DevTask& t, int B, int b, MftIn& in) {
-	const real* G = t.goals;
+	const real* G = t.law_goals;  // goal, or the internal OTG's next state (MotionForceTask.cpp:386-407)
 	UNROLL for (int k = 0; k < 3; k++) {
 		in.g_pos[k] = ld(G, k, B, b);
 		in.g_v[k] = ld(G, 12 + k, B, b);
@@ -384,8 +384,8 @@ DI void mft_load(const DevTask& t, int B, int b, MftIn& in) {
 	UNROLL for (int k = 6; k < 12; k++) in.integ[k] = 0;
 	if ((t.fdim | t.mdim) != 0) {  // batch-uniform
 		UNROLL for (int k = 0; k < 3; k++) {
-			in.g_f[k] = ld(G, 24 + k, B, b);
-			in.g_m[k] = ld(G, 27 + k, B, b);
+			in.g_f[k] = ld(t.goals, 24 + k, B, b);
+			in.g_m[k] = ld(t.goals, 27 + k, B, b);
 		}
 		if (t.cl_force || t.cl_moment) {
 			UNROLL for (int k = 0; k < 3; k++) {
@@ -1173,7 +1173,7 @@ DI void jt_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B,
 		mv<N, N>(t.S, rc.dq, vel);
 	}
 	if (!zero_range) {
-		const real* G = t.goals;
+		const real* G = t.law_goals;  // goal, or the internal OTG's next state (JointTask.cpp:308-320)
 		UNROLL for (int i = 0; i < N; i++) {
 			f[i] = 0;
 			ddq_d[i] = 0;

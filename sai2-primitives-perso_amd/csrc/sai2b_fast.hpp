@@ -70,7 +70,7 @@ struct JtEarly {
 	real f[N], ddq[N], integ[N];
 };
 DI void fast_jt_early(const DevTask& t1, const RobotCtx& rc, int B, int b, JtEarly& e) {
-	const real* G = t1.goals;
+	const real* G = t1.law_goals;
 	UNROLL for (int i = 0; i < N; i++) {  // JointTask.cpp:299-345, S = I
 		const real qd = ld(G, i, B, b), dqd = ld(G, N + i, B, b);
 		e.ddq[i] = ld(G, 2 * N + i, B, b);

@@ -218,7 +218,11 @@ extern "C" int sai2b_default_joint_task(sai2b_task_config* c, const char* name, 
 	for (int i = 0; i < N; i++) {
 		c->kp[i] = 50.0, c->kv[i] = 14.0, c->ki[i] = 0.0;  // JointTask.h:32-34
 		c->saturation_velocity[i] = M_PI / 3.0;				 // JointTask.h:44
+		c->otg_max_velocity[i] = M_PI / 3.0;				 // JointTask.h:40
+		c->otg_max_acceleration[i] = 2.0 * M_PI;			 // JointTask.h:41
 	}
+	c->use_internal_otg = 1;  // JointTask.h:38-39: on, acceleration-limited
+	c->internal_otg_jerk_limited = 0;
 	return SAI2B_OK;
 }
 
@@ -269,6 +273,10 @@ extern "C" int sai2b_default_motion_force_task(sai2b_task_config* c, const char*
 	c->linear_saturation_velocity = 0.3, c->angular_saturation_velocity = M_PI / 3;
 	c->sensor_rot[0] = c->sensor_rot[4] = c->sensor_rot[8] = 1.0;
 	singularity_defaults(c);
+	c->use_internal_otg = 1;  // MotionForceTask.h:67-72: on, acceleration-limited
+	c->internal_otg_jerk_limited = 0;
+	c->otg_max_linear_velocity = 0.3, c->otg_max_linear_acceleration = 2.0;
+	c->otg_max_angular_velocity = M_PI / 3, c->otg_max_angular_acceleration = 2.0 * M_PI;
 	return SAI2B_OK;
 }
 
@@ -310,6 +318,22 @@ extern "C" int sai2b_validate_tasks(const sai2b_task_config* tasks, int n_tasks,
 			for (int k = 0; err.empty() && k < 3; k++)
 				if (t.kp_pos[k] < 0 || t.kv_pos[k] < 0 || t.ki_pos[k] < 0 || t.kp_ori[k] < 0 || t.kv_ori[k] < 0 || t.ki_ori[k] < 0)
 					err = "all gains should be positive or zero in MotionForceTask::setPosControlGains\n";
+		}
+		if (err.empty() && t.use_internal_otg) {
+			if (t.internal_otg_jerk_limited)
+				err = "the jerk-limited internal OTG (enableInternalOtgJerkLimited) is not implemented in this build";
+			else if (t.type == SAI2B_JOINT_TASK) {
+				for (int k = 0; err.empty() && k < t.task_dof; k++) {
+					if (!(t.otg_max_velocity[k] > 0))
+						err = "max velocity cannot be 0 or negative in any directions in OTG_joints::setMaxVelocity\n";
+					else if (!(t.otg_max_acceleration[k] > 0))
+						err = "max acceleration cannot be 0 or negative in any directions in OTG_joints::setMaxAcceleration\n";
+				}
+			} else if (!(t.otg_max_linear_velocity > 0) || !(t.otg_max_angular_velocity > 0)) {
+				err = "max velocity set to 0 or negative value in some directions in OTG_6dof_cartesian::setMaxLinearVelocity\n";
+			} else if (!(t.otg_max_linear_acceleration > 0) || !(t.otg_max_angular_acceleration > 0)) {
+				err = "max acceleration set to 0 or negative value in some directions in OTG_6dof_cartesian::setMaxLinearAcceleration\n";
+			}
 		}
 		if (err.empty() && t.use_velocity_saturation) {
 			if (t.type == SAI2B_MOTION_FORCE_TASK && (t.linear_saturation_velocity <= 0 || t.angular_saturation_velocity <= 0))
@@ -422,6 +446,18 @@ static void fill_dev_task(const sai2b_task_config& c, DevTask& d) {
 	d.sh_cap = c.sh_buffer_size;
 	d.kp1 = c.kp_type_1, d.kv1 = c.kv_type_1, d.kv2 = c.kv_type_2;
 	d.enforce_t1 = c.enforce_type_1_strategy, d.enforce = c.enforce_handling_strategy;
+	// internal OTG: one generator DoF per task dof (JT) or 3 linear + 3 angular (MFT)
+	d.otg_on = c.use_internal_otg ? 1 : 0;
+	d.otg_n = c.type == SAI2B_JOINT_TASK ? c.task_dof : 6;
+	for (int i = 0; i < N; i++) {
+		if (c.type == SAI2B_JOINT_TASK) {
+			d.otg_vmax[i] = i < c.task_dof ? c.otg_max_velocity[i] : 0.0;
+			d.otg_amax[i] = i < c.task_dof ? c.otg_max_acceleration[i] : 0.0;
+		} else {
+			d.otg_vmax[i] = i < 3 ? c.otg_max_linear_velocity : i < 6 ? c.otg_max_angular_velocity : 0.0;
+			d.otg_amax[i] = i < 3 ? c.otg_max_linear_acceleration : i < 6 ? c.otg_max_angular_acceleration : 0.0;
+		}
+	}
 }
 
 template <class T>
@@ -512,6 +548,12 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 			if ((rc = dev_alloc(ctx, &d.goals, 3 * (size_t)d.k0 * Bs))) return rc;
 			if ((rc = dev_alloc(ctx, &d.state, (size_t)d.k0 * Bs))) return rc;
 		}
+		// the OTG objects exist (and follow reinitialize) whether or not the OTG is enabled
+		const size_t goal_rows = tasks[t].type == SAI2B_MOTION_FORCE_TASK ? (size_t)sai2b::MFT_GOAL_ROWS : 3 * (size_t)d.k0;
+		if ((rc = dev_alloc(ctx, &d.otg_desired, goal_rows * Bs))) return rc;
+		if ((rc = dev_alloc(ctx, &d.otg_state, (size_t)sai2b::OTG_ROWS * Bs))) return rc;
+		d.otg_epoch = 0.0;
+		d.law_goals = d.otg_on ? d.otg_desired : d.goals;
 	}
 	for (int t = 0; t < n_tasks; t++)
 		if (tasks[t].type == SAI2B_MOTION_FORCE_TASK && tasks[t].passivity_enabled && (rc = popc_reinit(ctx, t))) return rc;
@@ -519,6 +561,8 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	if ((rc = upload_params(ctx))) return rc;
 	// the reference constructs tasks from the model's current state (q = 0 until set_state)
 	if (sai2b_launch_reinit(ctx->d_params, ctx->B, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "reinit launch failed");
+	if (sai2b_launch_otg_reinit(ctx->d_params, ctx->B, -1, 0, ctx->stream))
+		return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG reinit launch failed");
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return SAI2B_OK;
 }
@@ -584,7 +628,23 @@ extern "C" int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_ta
 	d.goals = keep.goals, d.sensed = keep.sensed, d.state = keep.state, d.istate = keep.istate;
 	d.dbg_tau = keep.dbg_tau, d.dbg_N = keep.dbg_N, d.dbg_sigma = keep.dbg_sigma, d.dbg_J = keep.dbg_J, d.dbg_pose = keep.dbg_pose;
 	d.dbg_F = keep.dbg_F;
+	d.otg_desired = keep.otg_desired, d.otg_state = keep.otg_state, d.otg_epoch = keep.otg_epoch;
+	d.law_goals = d.otg_on ? d.otg_desired : d.goals;
 	ctx->params_dirty = true;
+	// enableInternalOtgAccelerationLimited (JointTask.cpp:360-381, MotionForceTask.cpp:511-523) is
+	// applied when the OTG fields change: new limits make every moving robot re-plan
+	// (InputParameter::operator!=, input_parameter.hpp:362-394); a generator that was off is
+	// re-initialised at the current state first
+	const bool limits_changed = std::memcmp(d.otg_vmax, keep.otg_vmax, sizeof(d.otg_vmax)) != 0 ||
+								std::memcmp(d.otg_amax, keep.otg_amax, sizeof(d.otg_amax)) != 0;
+	if (d.otg_on && (limits_changed || !keep.otg_on)) {
+		if (limits_changed) d.otg_epoch += 1.0;
+		int rc3 = upload_params(ctx);
+		if (rc3) return rc3;
+		if (sai2b_launch_otg_reinit(ctx->d_params, ctx->B, task, keep.otg_on ? 2 : 1, ctx->stream))
+			return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG enable launch failed");
+		ctx->launches++;
+	}
 	return SAI2B_OK;
 }
 
@@ -671,7 +731,9 @@ extern "C" int sai2b_reinitialize(sai2b_ctx* ctx) {
 	int rc = upload_params(ctx);
 	if (rc) return rc;
 	if (sai2b_launch_reinit(ctx->d_params, ctx->B, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "reinit launch failed");
-	ctx->launches++;
+	if (sai2b_launch_otg_reinit(ctx->d_params, ctx->B, -1, 0, ctx->stream))
+		return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG reinit launch failed");
+	ctx->launches += 2;
 	ctx->models_fresh = false;
 	return SAI2B_OK;
 }
@@ -687,11 +749,21 @@ static int fast_kind(const sai2b_ctx* ctx) {
 	return (ctx->cfg[1].type == SAI2B_JOINT_TASK && ctx->h_params.task[1].full_selection) ? 2 : 0;
 }
 
+static bool any_otg(const sai2b_ctx* ctx) {
+	for (int t = 0; t < ctx->T; t++)
+		if (ctx->h_params.task[t].otg_on) return true;
+	return false;
+}
+
 static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torque) {
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	int rc = upload_params(ctx);
 	if (rc) return rc;
 	const int fast = fast_kind(ctx);
+	if (do_torque && any_otg(ctx)) {  // the generators advance once per torque computation, before the law
+		if (sai2b_launch_otg(ctx->d_params, ctx->B, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG launch failed");
+		ctx->launches++;
+	}
 	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, ctx->baked_model ? 1 : 0, commit_sh, with_comp, do_torque, ctx->wave_flags, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
 	ctx->launches++;
@@ -817,6 +889,47 @@ extern "C" int sai2b_get_mft_task_forces(sai2b_ctx* ctx, int task, double* F_uni
 	if ((rc = fetch_dbg(ctx, F_unit, F, 6))) return rc;
 	return fetch_dbg(ctx, F_force, F ? F + 6 * (size_t)ctx->B : nullptr, 6);
 }
+// rows of a device buffer to host arrays (any destination may be NULL)
+static int fetch_rows(sai2b_ctx* ctx, const double* src, size_t row0, size_t rows, double* dst) {
+	if (!dst) return SAI2B_OK;
+	HIP_TRY(ctx, hipMemcpyAsync(dst, src + row0 * (size_t)ctx->B, rows * (size_t)ctx->B * sizeof(double), hipMemcpyDeviceToHost,
+								ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return SAI2B_OK;
+}
+extern "C" int sai2b_get_jt_desired(sai2b_ctx* ctx, int task, double* q, double* dq, double* ddq) {
+	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	if (task < 0 || task >= ctx->T || ctx->cfg[task].type != SAI2B_JOINT_TASK)
+		return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_get_jt_desired: task is not a JointTask");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const double* G = ctx->h_params.task[task].law_goals;
+	const size_t k0 = ctx->cfg[task].task_dof;
+	int rc;
+	if ((rc = fetch_rows(ctx, G, 0, k0, q))) return rc;
+	if ((rc = fetch_rows(ctx, G, k0, k0, dq))) return rc;
+	return fetch_rows(ctx, G, 2 * k0, k0, ddq);
+}
+extern "C" int sai2b_get_mft_desired(sai2b_ctx* ctx, int task, double* pos, double* rot, double* lin_vel, double* ang_vel,
+									 double* lin_acc, double* ang_acc) {
+	int rc = mft_task_check(ctx, task, "sai2b_get_mft_desired");
+	if (rc) return rc;
+	const double* G = ctx->h_params.task[task].law_goals;
+	if ((rc = fetch_rows(ctx, G, 0, 3, pos))) return rc;
+	if ((rc = fetch_rows(ctx, G, 3, 9, rot))) return rc;
+	if ((rc = fetch_rows(ctx, G, 12, 3, lin_vel))) return rc;
+	if ((rc = fetch_rows(ctx, G, 15, 3, ang_vel))) return rc;
+	if ((rc = fetch_rows(ctx, G, 18, 3, lin_acc))) return rc;
+	return fetch_rows(ctx, G, 21, 3, ang_acc);
+}
+extern "C" int sai2b_get_otg_status(sai2b_ctx* ctx, int task, double* goal_reached, double* result) {
+	if (!ctx || task < 0 || task >= ctx->T) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_get_otg_status: bad arguments");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const double* S = ctx->h_params.task[task].otg_state;
+	int rc = fetch_rows(ctx, S, sai2b::OTG_GOAL_REACHED, 1, goal_reached);
+	if (rc) return rc;
+	return fetch_rows(ctx, S, sai2b::OTG_RESULT, 1, result);
+}
+
 extern "C" int sai2b_get_model(sai2b_ctx* ctx, int task, double* M, double* J, double* pos, double* rot) {
 	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
 	int rc;

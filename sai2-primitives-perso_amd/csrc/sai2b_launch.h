@@ -12,3 +12,6 @@ extern "C" int sai2b_launch_reinit(const sai2b::DevParams* d_params, int B, hipS
 extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int part,
 									  int* wave_flags,
 									  hipStream_t stream);
+// internal OTG (sai2b_otg.hip): one update of every enabled generator; (re)initialisation (modes in the kernel's comment)
+extern "C" int sai2b_launch_otg(const sai2b::DevParams* d_params, int B, hipStream_t stream);
+extern "C" int sai2b_launch_otg_reinit(const sai2b::DevParams* d_params, int B, int only_task, int mode, hipStream_t stream);

@@ -559,6 +559,7 @@ struct Gen {
 	double time;
 	Traj traj;
 	int goal_reached, result, target_set, ci_init;
+	int replanned;	  // the last ruckig_update computed a new trajectory (OutputParameter::new_calculation)
 	double ci_epoch;  // limits generation the stored current_input was planned with
 	// OTG_6dof_cartesian only
 	double ref[9], goal_R[9], goal_w[3];
@@ -578,6 +579,7 @@ SAI2B_HD bool input_differs(const Gen& g, int n, double epoch) {
 SAI2B_HD int ruckig_update(Gen& g, int n, double dt, const double (&vmax)[MAXD], const double (&amax)[MAXD],
 						   double epoch) {
 	int result = WORKING;
+	g.replanned = 0;
 	if (input_differs(g, n, epoch) || !g.ci_init) {
 		if (!validate(g.in, n, vmax, amax)) return ERR_INVALID_INPUT;
 		Traj tr;
@@ -588,6 +590,7 @@ SAI2B_HD int ruckig_update(Gen& g, int n, double dt, const double (&vmax)[MAXD],
 		g.ci_epoch = epoch;
 		g.ci_init = 1;
 		g.time = 0.0;
+		g.replanned = 1;
 	}
 	g.time += dt;
 #pragma unroll

@@ -55,8 +55,16 @@ struct DevTask {
 	int sh_cap;
 	double kp1, kv1, kv2;
 	int enforce_t1, enforce;
+	// internal OTG (JointTask.h:38-42, MotionForceTask.h:67-74); limits per OTG DoF (JT: task dof;
+	// MFT: 3 linear then 3 angular)
+	int otg_on, otg_n;
+	double otg_vmax[N], otg_amax[N];
+	double otg_epoch;  // bumped when the limits change: every moving robot re-plans on its next tick
 	// device buffers of this task
 	double* goals;	// MFT [30][B]: pos3 rot9 v3 w3 a3 alpha3 f3 m3 ; JT [3*k0][B]: q dq ddq
+	double* law_goals;	 // what the control law tracks: `goals`, or `otg_desired` when the OTG is on
+	double* otg_desired; // same layout as goals; written by otg_kernel (MFT: rows 0..23)
+	double* otg_state;	 // [OTG_ROWS][B], see the OTG_* row constants
 	double* sensed; // MFT [6][B]
 	double* state;	// MFT [33][B]: integ pos3 ori3 f3 m3, q_prior7, dq_prior7, t2dir7 ; JT [k0][B]
 	int* istate;	// MFT [12][B]: hist words 0..6, n_types, count, size, c1, c2
@@ -73,6 +81,17 @@ struct DevTask {
 };
 
 constexpr int MFT_GOAL_ROWS = 30;
+constexpr int MFT_MOTION_GOAL_ROWS = 24;  // pos rot v w a alpha: the rows the OTG replaces
+// rows of otg_state (one OTG_joints / OTG_6dof_cartesian object per robot; sai2b_otg_core.hpp: Gen)
+constexpr int OTG_IN = 0;	  // wrapper _input: cp cv ca tp tv, 7 rows each
+constexpr int OTG_CI = 35;	  // Ruckig current_input: cp cv ca tp tv
+constexpr int OTG_OUT = 70;	  // _output: new position, velocity, acceleration
+constexpr int OTG_TIME = 91, OTG_DURATION = 92, OTG_GOAL_REACHED = 93, OTG_RESULT = 94, OTG_TARGET_SET = 95,
+			  OTG_CI_INIT = 96, OTG_CI_EPOCH = 97, OTG_CONSTRUCTED = 98;
+constexpr int OTG_TRAJ = 99;  // per DoF: brake t a p v, p0 v0, t0 t1 t2 t6, a0 a2 a6
+constexpr int OTG_TRAJ_STRIDE = 13;
+constexpr int OTG_CART = OTG_TRAJ + 7 * OTG_TRAJ_STRIDE;  // reference frame 9, goal orientation 9, goal angular velocity 3
+constexpr int OTG_ROWS = OTG_CART + 21;
 constexpr int MFT_STATE_ROWS = 33;
 constexpr int MFT_ISTATE_ROWS = 12;
 constexpr int POPC_RING = 1024;	 // capacity of the PO window ring (the reference queue is unbounded)

@@ -86,6 +86,7 @@ static int tick(int B, const char* path) {
 	auto mft = std::make_shared<MotionForceTask>(robot, 6, pos);
 	mft->disableInternalOtg();
 	auto jt = std::make_shared<JointTask>(robot);
+	jt->disableInternalOtg();
 	std::vector<std::shared_ptr<TemplateTask>> tasks = {mft, jt};
 	RobotController ctl(robot, tasks);
 	mft->setGoalPosition(rd(3));

@@ -315,6 +315,8 @@ def test_facade_mirrors_reference_api():
     mft = pkg.MotionForceTask(robot, task_name="ee")
     mft.disableInternalOtg()
     jt = pkg.JointTask(robot)
+    assert jt.getInternalOtgEnabled() and not mft.getInternalOtgEnabled()  # on by default (JointTask.h:38)
+    jt.disableInternalOtg()
     ctl = pkg.RobotController(robot, [mft, jt])
     assert ctl.getTaskNames() == ["ee", "joint_task"]
     assert ctl.getMotionForceTaskByName("ee") is mft
