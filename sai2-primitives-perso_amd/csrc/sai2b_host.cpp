@@ -32,6 +32,9 @@ struct sai2b_ctx {
 	bool baked_model = false;  // the ctx model is bit-equal to the compile-time Panda constants
 	bool no_fast_path = false;	// SAI2B_NO_FAST_PATH=1 in the environment: always run the generic kernel
 	int* wave_flags = nullptr;	// per-wavefront "needs the generic path" flags of the fast kernel
+	int* otg_counts = nullptr;	// [2][MAX_TASKS] work-list counters of the trajectory planner (sai2b_otg.hip)
+	int* otg_list = nullptr;	// [MAX_TASKS][B] robots that need the planner this tick
+	int otg_parity = 0;
 	sai2b_robot_model model;
 	sai2b_task_config cfg[SAI2B_MAX_TASKS];
 	DevParams h_params;
@@ -535,6 +538,8 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	if ((rc = dev_alloc(ctx, &ctx->tau, N * Bs))) return rc;
 	hp.q = ctx->q, hp.dq = ctx->dq, hp.tau = ctx->tau;
 	if ((rc = dev_alloc(ctx, &ctx->wave_flags, (Bs + 63) / 64))) return rc;
+	if ((rc = dev_alloc(ctx, &ctx->otg_counts, 2 * SAI2B_MAX_TASKS))) return rc;
+	if ((rc = dev_alloc(ctx, &ctx->otg_list, SAI2B_MAX_TASKS * Bs))) return rc;
 	for (int t = 0; t < n_tasks; t++) {
 		ctx->cfg[t] = tasks[t];
 		DevTask& d = hp.task[t];
@@ -761,8 +766,9 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 	if (rc) return rc;
 	const int fast = fast_kind(ctx);
 	if (do_torque && any_otg(ctx)) {  // the generators advance once per torque computation, before the law
-		if (sai2b_launch_otg(ctx->d_params, ctx->B, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG launch failed");
-		ctx->launches++;
+		if (sai2b_launch_otg(ctx->d_params, ctx->B, ctx->otg_counts, ctx->otg_list, ctx->otg_parity, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG launch failed");
+		ctx->otg_parity ^= 1;
+		ctx->launches += 2;
 	}
 	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, ctx->baked_model ? 1 : 0, commit_sh, with_comp, do_torque, ctx->wave_flags, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");

@@ -9,9 +9,12 @@
 // contraction (Makefile: -ffp-contract=off) so that the planner's accept/reject tests see the same
 // arithmetic as the reference's CPU build.
 //
-// Memory: the state of one generator is OTG_ROWS doubles per robot (SoA rows of otg_state). A robot
-// whose goal is reached and unchanged touches ~30 of them and writes nothing; a moving robot reads
-// all and writes back the ~70 that change every tick (the trajectory rows only when it re-planned).
+// Two kernels per tick. otg_kernel classifies every robot: goal reached and unchanged -> nothing to
+// do (~35 rows read, nothing written); moving on its stored trajectory -> sampled right there (~180
+// rows read, ~85 written: state is OTG_ROWS doubles per robot, SoA rows of otg_state); goal changed or
+// input differs -> appended to a work list. otg_plan_kernel runs the planner on the compacted list,
+// so a tick in which 1 % of the robots get a new goal costs 1 % of the planner's time, not one
+// divergent lane in every wavefront.
 #include <hip/hip_runtime.h>
 
 #include "sai2b_device.hpp"
@@ -150,66 +153,213 @@ DI void limits_of(const DevTask& t, double (&vmax)[MD], double (&amax)[MD]) {
 	UNROLL for (int d = 0; d < MD; d++) vmax[d] = t.otg_vmax[d], amax[d] = t.otg_amax[d];
 }
 
-// one task, one robot, one tick
-DI void otg_task_tick(const DevTask& t, int B, int b) {
-	real* S = t.otg_state;
-	const bool cart = t.type == SAI2B_MOTION_FORCE_TASK;
-	const int n = t.otg_n;
-	Gen g;
+// goals of one robot as the wrappers' setGoal... calls take them
+struct Goals {
+	double jp[MD], jv[MD];			  // JointTask: position, velocity
+	real cp[3], cR[9], cv[3], cw[3];  // MotionForceTask: position, orientation, linear/angular velocity
+};
+DI void load_goals(const DevTask& t, bool cart, int n, int B, int b, Goals& G) {
+	if (!cart) {
+		load7(t.goals, 0, n, B, b, G.jp);
+		load7(t.goals, n, n, B, b, G.jv);
+	} else {
+		UNROLL for (int k = 0; k < 3; k++) {
+			G.cp[k] = ld(t.goals, k, B, b);
+			G.cv[k] = ld(t.goals, 12 + k, B, b);
+			G.cw[k] = ld(t.goals, 15 + k, B, b);
+		}
+		UNROLL for (int k = 0; k < 9; k++) G.cR[k] = ld(t.goals, 3 + k, B, b);
+	}
+}
+
+// What this tick means for one generator:
+//   IDLE    goal reached and unchanged: update() returns at once, nothing to read or write;
+//   SAMPLE  goal unchanged, input equal to Ruckig's stored one: advance along the stored trajectory;
+//   PLAN    the goal changed (setGoal... will touch the input) or the input differs from the stored
+//           one (ruckig.hpp:194): the full update with the planner, done by otg_plan_kernel.
+enum { IDLE = 0, SAMPLE = 1, PLAN = 2 };
+DI int classify(const DevTask& t, bool cart, int n, int B, int b, Gen& g, Goals& G) {
+	const real* S = t.otg_state;
 	load_head(S, n, cart, B, b, g);
+	load_goals(t, cart, n, B, b, G);
+	bool unchanged;
+	if (!cart) {
+		unchanged = g.target_set && otg::approx_range(G.jp, g.in.tp, 0, n, 1e-12) && otg::approx_range(G.jv, g.in.tv, 0, n, 1e-12);
+	} else {
+		const double p7[MD] = {G.cp[0], G.cp[1], G.cp[2], 0, 0, 0, 0}, v7[MD] = {G.cv[0], G.cv[1], G.cv[2], 0, 0, 0, 0};
+		unchanged = (g.target_set & 1) && otg::approx_range(p7, g.in.tp, 0, 3, 1e-3) && otg::approx_range(v7, g.in.tv, 0, 3, 1e-3) &&
+					(g.target_set & 2) && otg::approx9(g.goal_R, G.cR, 9, 1e-3) && otg::approx9(g.goal_w, G.cw, 3, 1e-3);
+	}
+	if (!unchanged) return PLAN;
+	if (g.goal_reached) return IDLE;
+	load7(S, OTG_IN, n, B, b, g.in.cp);
+	load7(S, OTG_IN + MD, n, B, b, g.in.cv);
+	load7(S, OTG_IN + 2 * MD, n, B, b, g.in.ca);
+	load7(S, OTG_CI, n, B, b, g.ci.cp);
+	load7(S, OTG_CI + MD, n, B, b, g.ci.cv);
+	load7(S, OTG_CI + 2 * MD, n, B, b, g.ci.ca);
+	load7(S, OTG_CI + 3 * MD, n, B, b, g.ci.tp);
+	load7(S, OTG_CI + 4 * MD, n, B, b, g.ci.tv);
+	g.ci_init = ldflag(S, OTG_CI_INIT, B, b);
+	g.ci_epoch = ld(S, OTG_CI_EPOCH, B, b);
+	return otg::needs_plan(g, n, t.otg_epoch) ? PLAN : SAMPLE;
+}
+
+DI void load_traj(const real* S, int n, bool cart, int B, int b, Gen& g) {
+	g.time = ld(S, OTG_TIME, B, b);
+	g.traj.duration = ld(S, OTG_DURATION, B, b);
+	UNROLL for (int d = 0; d < MD; d++) {
+		otg::Dof& f = g.traj.dof[d];
+		otg::Prof& p = g.traj.prof[d];
+		if (d < n) {
+			const int r = OTG_TRAJ + d * OTG_TRAJ_STRIDE;
+			f.brake_t = ld(S, r, B, b), f.brake_a = ld(S, r + 1, B, b), f.brake_p = ld(S, r + 2, B, b);
+			f.brake_v = ld(S, r + 3, B, b), f.p0 = ld(S, r + 4, B, b), f.v0 = ld(S, r + 5, B, b);
+			p.t0 = ld(S, r + 6, B, b), p.t1 = ld(S, r + 7, B, b), p.t2 = ld(S, r + 8, B, b), p.t6 = ld(S, r + 9, B, b);
+			p.a0 = ld(S, r + 10, B, b), p.a2 = ld(S, r + 11, B, b), p.a6 = ld(S, r + 12, B, b);
+			p.dur = ((p.t0 + p.t1) + p.t2) + p.t6;
+		}
+	}
+	if (cart) {
+		UNROLL for (int i = 0; i < 9; i++) g.ref[i] = ld(S, OTG_CART + i, B, b);
+	}
+}
+
+// SAMPLE: Ruckig::update without a new calculation, then the wrapper's bookkeeping
+DI void sample_lane(const DevTask& t, bool cart, int n, int B, int b, Gen& g) {
+	real* S = t.otg_state;
+	load_traj(S, n, cart, B, b, g);
+	const int target_set0 = g.target_set;
+	g.result = otg::ruckig_sample(g, n, t.dt, otg::WORKING);
+	otg::Prev none;	 // the error branch cannot be taken without a calculation
+	if (cart)
+		otg::cart_finish(g, none);
+	else
+		otg::joints_finish(g, n, none);
+	store7(S, OTG_IN, n, B, b, g.in.cp);
+	store7(S, OTG_IN + MD, n, B, b, g.in.cv);
+	store7(S, OTG_IN + 2 * MD, n, B, b, g.in.ca);
+	store7(S, OTG_CI, n, B, b, g.ci.cp);
+	store7(S, OTG_CI + MD, n, B, b, g.ci.cv);
+	store7(S, OTG_CI + 2 * MD, n, B, b, g.ci.ca);
+	store7(S, OTG_OUT, n, B, b, g.np);
+	store7(S, OTG_OUT + MD, n, B, b, g.nv);
+	store7(S, OTG_OUT + 2 * MD, n, B, b, g.na);
+	st(S, OTG_TIME, B, b, g.time);
+	st(S, OTG_RESULT, B, b, (double)g.result);
+	if (g.result == otg::FINISHED) {  // goal reached, or re-targeted to stop (rare): the head changes too
+		st(S, OTG_GOAL_REACHED, B, b, (double)g.goal_reached);
+		if (!g.goal_reached) {
+			store7(S, OTG_IN + 3 * MD, n, B, b, g.in.tp);
+			store7(S, OTG_IN + 4 * MD, n, B, b, g.in.tv);
+			st(S, OTG_TARGET_SET, B, b, (double)g.target_set);
+			if (cart) {
+				UNROLL for (int i = 0; i < 9; i++) st(S, OTG_CART + i, B, b, g.ref[i]);
+				UNROLL for (int i = 0; i < 9; i++) st(S, OTG_CART + 9 + i, B, b, g.goal_R[i]);
+				UNROLL for (int i = 0; i < 3; i++) st(S, OTG_CART + 18 + i, B, b, g.goal_w[i]);
+			}
+		}
+	}
+	(void)target_set0;
+	if (cart)
+		store_desired_cart(t.otg_desired, B, b, g);
+	else
+		store_desired_joints(t.otg_desired, n, B, b, g);
+}
+
+// PLAN: the whole computeTorques-time sequence setGoal...(goal); update(); (JointTask.cpp:314-315,
+// MotionForceTask.cpp:395-399) with one call site of the planner for both wrapper kinds
+DI void plan_lane(const DevTask& t, bool cart, int n, int B, int b, Gen& g, const Goals& G) {
+	real* S = t.otg_state;
+	load_body(S, n, cart, B, b, g);
 	double vmax[MD], amax[MD];
 	limits_of(t, vmax, amax);
-	if (!cart) {
-		double gp[MD], gv[MD];
-		load7(t.goals, 0, n, B, b, gp);
-		load7(t.goals, n, n, B, b, gv);
-		otg::joints_set_goal(g, n, gp, gv);
-		if (g.goal_reached) return;	 // nothing moves: otg_desired already holds the final state
-		load_body(S, n, false, B, b, g);
-		g.replanned = 0;
-		otg::joints_update(g, n, t.dt, vmax, amax, t.otg_epoch);
-		store_state(S, n, false, B, b, g);
-		if (g.replanned) store_traj(S, n, B, b, g);
-		store_desired_joints(t.otg_desired, n, B, b, g);
+	if (cart) {
+		otg::cart_set_goal_position(g, G.cp, G.cv);
+		otg::cart_set_goal_orientation(g, G.cR, G.cw);
 	} else {
-		real gp[3], gR[9], gv[3], gw[3];
-		UNROLL for (int k = 0; k < 3; k++) {
-			gp[k] = ld(t.goals, k, B, b);
-			gv[k] = ld(t.goals, 12 + k, B, b);
-			gw[k] = ld(t.goals, 15 + k, B, b);
-		}
-		UNROLL for (int k = 0; k < 9; k++) gR[k] = ld(t.goals, 3 + k, B, b);
-		// setGoalOrientationAndAngularVelocity re-references the frame from the current output, so
-		// the body is needed before it whenever a goal changes; the idle test only needs the head
-		const double p7[MD] = {gp[0], gp[1], gp[2], 0, 0, 0, 0}, v7[MD] = {gv[0], gv[1], gv[2], 0, 0, 0, 0};
-		const bool same_pos = (g.target_set & 1) && otg::approx_range(p7, g.in.tp, 0, 3, 1e-3) &&
-							  otg::approx_range(v7, g.in.tv, 0, 3, 1e-3);
-		const bool same_ori = (g.target_set & 2) && otg::approx9(g.goal_R, gR, 9, 1e-3) && otg::approx9(g.goal_w, gw, 3, 1e-3);
-		if (g.goal_reached && same_pos && same_ori) return;
-		load_body(S, 6, true, B, b, g);
-		otg::cart_set_goal_position(g, gp, gv);
-		otg::cart_set_goal_orientation(g, gR, gw);
-		g.replanned = 0;
-		otg::cart_update(g, t.dt, vmax, amax, t.otg_epoch);
-		store_state(S, 6, true, B, b, g);
-		if (g.replanned) store_traj(S, 6, B, b, g);
-		store_desired_cart(t.otg_desired, B, b, g);
+		otg::joints_set_goal(g, n, G.jp, G.jv);
 	}
+	g.replanned = 0;
+	if (!g.goal_reached) {
+		otg::Prev pv;
+		otg::save_prev(g, pv);
+		g.result = otg::ruckig_update(g, n, t.dt, vmax, amax, t.otg_epoch);
+		if (cart)
+			otg::cart_finish(g, pv);
+		else
+			otg::joints_finish(g, n, pv);
+	}
+	store_state(S, n, cart, B, b, g);
+	if (g.replanned) store_traj(S, n, B, b, g);
+	if (cart)
+		store_desired_cart(t.otg_desired, B, b, g);
+	else
+		store_desired_joints(t.otg_desired, n, B, b, g);
 }
 
 }  // namespace
 
-// every task with its OTG on, one robot per lane
-__global__ __launch_bounds__(64) void otg_kernel(const DevParams* __restrict__ Pp) {
+// Work list of the planner: per task a counter and the robot indices that need it this tick.
+// Two counter sets alternate between ticks (`parity`): the plan kernel of tick k clears the set of
+// tick k+1, so no extra clearing launch is needed.
+//   counts: [2][SAI2B_MAX_TASKS] ints          list: [SAI2B_MAX_TASKS][B] ints
+
+// Every generator that is on, one robot per lane: idle and sampling robots are finished here; robots
+// that need the planner are appended to the task's work list (one atomic per wavefront, lanes of a
+// wavefront stay adjacent and ordered, so the plan kernel's accesses coalesce in runs).
+__global__ __launch_bounds__(64) void otg_kernel(const DevParams* __restrict__ Pp, int* __restrict__ counts,
+												 int* __restrict__ list, int parity) {
 	const DevParams& P = *Pp;
 	const int B = P.B;
 	const int b = blockIdx.x * 64 + threadIdx.x;
-	if (b >= B) return;
+	const bool live = b < B;
 #pragma unroll 1
 	for (int t = 0; t < P.n_tasks; t++) {
 		const DevTask& tk = P.task[t];
 		if (!tk.otg_on) continue;
-		otg_task_tick(tk, B, b);
+		const bool cart = tk.type == SAI2B_MOTION_FORCE_TASK;
+		int cls = IDLE;
+		if (live) {
+			Gen g;
+			Goals G;
+			cls = classify(tk, cart, tk.otg_n, B, b, g, G);
+			if (cls == SAMPLE) sample_lane(tk, cart, tk.otg_n, B, b, g);
+		}
+		const unsigned long long mask = __ballot(cls == PLAN);
+		if (mask) {
+			int base = 0;
+			if (threadIdx.x == 0) base = atomicAdd(&counts[parity * SAI2B_MAX_TASKS + t], __popcll(mask));
+			base = __shfl(base, 0);
+			if (cls == PLAN) {
+				const int pos = base + __popcll(mask & ((1ull << threadIdx.x) - 1ull));
+				((gint*)list)[(size_t)t * B + pos] = b;
+			}
+		}
+	}
+}
+
+// The robots otg_kernel left over (goal changed / input differs), compacted: lane i of the grid takes
+// entry i of the task's list. Classification is repeated from the untouched state, which also
+// re-loads what the full update needs.
+__global__ __launch_bounds__(64) void otg_plan_kernel(const DevParams* __restrict__ Pp, int* __restrict__ counts,
+													  const int* __restrict__ list, int parity) {
+	const DevParams& P = *Pp;
+	const int B = P.B;
+	const int i = blockIdx.x * 64 + threadIdx.x;
+	if (i < SAI2B_MAX_TASKS) ((gint*)counts)[(1 - parity) * SAI2B_MAX_TASKS + i] = 0;  // next tick's counters
+#pragma unroll 1
+	for (int t = 0; t < P.n_tasks; t++) {
+		const DevTask& tk = P.task[t];
+		if (!tk.otg_on) continue;
+		const int cnt = ((const gint*)counts)[parity * SAI2B_MAX_TASKS + t];
+		if (blockIdx.x * 64 >= cnt) continue;  // uniform over the wavefront
+		if (i >= cnt) continue;
+		const int b = ((const gint*)list)[(size_t)t * B + i];
+		const bool cart = tk.type == SAI2B_MOTION_FORCE_TASK;
+		Gen g;
+		Goals G;
+		if (classify(tk, cart, tk.otg_n, B, b, g, G) == PLAN) plan_lane(tk, cart, tk.otg_n, B, b, g, G);
 	}
 }
 
@@ -286,8 +436,13 @@ __global__ __launch_bounds__(64) void otg_reinit_kernel(const DevParams* __restr
 
 }  // namespace sai2b
 
-extern "C" int sai2b_launch_otg(const sai2b::DevParams* d_params, int B, hipStream_t stream) {
-	hipLaunchKernelGGL(sai2b::otg_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, d_params);
+// counts: [2][SAI2B_MAX_TASKS] ints, zero before the first call; list: [SAI2B_MAX_TASKS][B] ints;
+// parity alternates 0/1 between consecutive calls
+extern "C" int sai2b_launch_otg(const sai2b::DevParams* d_params, int B, int* counts, int* list, int parity,
+								hipStream_t stream) {
+	const dim3 grid((B + 63) / 64), block(64);
+	hipLaunchKernelGGL(sai2b::otg_kernel, grid, block, 0, stream, d_params, counts, list, parity);
+	hipLaunchKernelGGL(sai2b::otg_plan_kernel, grid, block, 0, stream, d_params, counts, (const int*)list, parity);
 	return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

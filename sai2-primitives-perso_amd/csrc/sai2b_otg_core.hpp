@@ -328,13 +328,12 @@ SAI2B_HD bool validate(const Input& in, int n, const double (&vmax)[MAXD], const
 // is_input_collinear (calculator_target.hpp:46-118), every DoF phase-synchronised, max_jerk = inf
 SAI2B_HD bool collinear(const Input& in, int n, const double (&amax)[MAXD], int limiting_direction,
 						int limiting_dof, double (&npc)[MAXD]) {
-	double pd[MAXD];
-#pragma unroll
-	for (int d = 0; d < MAXD; d++) pd[d] = in.tp[d] - in.cp[d];
-	int which = -1, scale_dof = -1;	 // which vector: 0 pd, 1 cv, 2 ca, 3 tv
-#pragma unroll
-	for (int d = 0; d < MAXD; d++)
-		if (d < n && scale_dof < 0) {
+	double pd[MAXD], sv[MAXD];
+	int which = -1, scale_dof = -1;	 // which vector scales: 0 pd, 1 cv, 2 ca, 3 tv
+#pragma unroll 1
+	for (int d = 0; d < n; d++) {
+		pd[d] = in.tp[d] - in.cp[d];
+		if (scale_dof < 0) {
 			if (fabs(pd[d]) > EPS)
 				which = 0, scale_dof = d;
 			else if (fabs(in.cv[d]) > EPS)
@@ -344,29 +343,25 @@ SAI2B_HD bool collinear(const Input& in, int n, const double (&amax)[MAXD], int 
 			else if (fabs(in.tv[d]) > EPS)
 				which = 3, scale_dof = d;
 		}
+	}
 	if (scale_dof < 0) return false;
-	double sv[MAXD];
-#pragma unroll
-	for (int d = 0; d < MAXD; d++) sv[d] = which == 0 ? pd[d] : which == 1 ? in.cv[d] : which == 2 ? in.ca[d] : in.tv[d];
-	const double scale = sel(sv, scale_dof);
-	const double pd_scale = sel(pd, scale_dof) / scale, v0_scale = sel(in.cv, scale_dof) / scale,
-				 vf_scale = sel(in.tv, scale_dof) / scale, a0_scale = sel(in.ca, scale_dof) / scale,
-				 af_scale = 0.0 / scale;
-	const double scale_limiting = sel(sv, limiting_dof);
-	const double control_limiting = (limiting_direction == 0) ? sel(amax, limiting_dof) : -sel(amax, limiting_dof);
-	bool ok = true;
-#pragma unroll
-	for (int d = 0; d < MAXD; d++)
-		if (d < n && ok) {
-			const double cs = sv[d];
-			if (fabs(pd[d] - pd_scale * cs) > EPS || fabs(in.cv[d] - v0_scale * cs) > EPS ||
-				fabs(in.ca[d] - a0_scale * cs) > EPS || fabs(in.tv[d] - vf_scale * cs) > EPS ||
-				fabs(0.0 - af_scale * cs) > EPS)
-				ok = false;
-			else
-				npc[d] = control_limiting * cs / scale_limiting;
-		}
-	return ok;
+#pragma unroll 1
+	for (int d = 0; d < n; d++) sv[d] = which == 0 ? pd[d] : which == 1 ? in.cv[d] : which == 2 ? in.ca[d] : in.tv[d];
+	const double scale = sv[scale_dof];
+	const double pd_scale = pd[scale_dof] / scale, v0_scale = in.cv[scale_dof] / scale,
+				 vf_scale = in.tv[scale_dof] / scale, a0_scale = in.ca[scale_dof] / scale, af_scale = 0.0 / scale;
+	const double scale_limiting = sv[limiting_dof];
+	const double control_limiting = (limiting_direction == 0) ? amax[limiting_dof] : -amax[limiting_dof];
+#pragma unroll 1
+	for (int d = 0; d < n; d++) {
+		const double cs = sv[d];
+		if (fabs(pd[d] - pd_scale * cs) > EPS || fabs(in.cv[d] - v0_scale * cs) > EPS ||
+			fabs(in.ca[d] - a0_scale * cs) > EPS || fabs(in.tv[d] - vf_scale * cs) > EPS ||
+			fabs(0.0 - af_scale * cs) > EPS)
+			return false;
+		npc[d] = control_limiting * cs / scale_limiting;
+	}
+	return true;
 }
 
 // TargetCalculator::calculate (calculator_target.hpp:249-532): acceleration-limited position
@@ -374,9 +369,11 @@ SAI2B_HD bool collinear(const Input& in, int n, const double (&amax)[MAXD], int 
 SAI2B_HD int calculate(const Input& in, int n, const double (&vmax)[MAXD], const double (&amax)[MAXD], Traj& tr) {
 	Block bl[MAXD];
 	bool failed = false;
-#pragma unroll
-	for (int d = 0; d < MAXD; d++)
-		if (d < n) {
+	// per-DoF loops stay rolled: the planner runs only when a goal changes, and compact code (dynamic
+	// indexing into per-lane scratch) beats seven inlined copies of step 1 / step 2
+#pragma unroll 1
+	for (int d = 0; d < n; d++) {
+		{
 			Dof& f = tr.dof[d];
 			const double vMax = vmax[d], vMin = -vmax[d], aMax = amax[d], aMin = -amax[d];
 			// brake.cpp:79-99, brake.hpp:66-75
@@ -399,6 +396,7 @@ SAI2B_HD int calculate(const Input& in, int n, const double (&vmax)[MAXD], const
 			}
 			if (!step1(f, bl[d], vMax, aMax)) failed = true;
 		}
+	}
 	if (failed) return ERR_EXECUTION_TIME;
 
 	if (n == 1) {
@@ -407,75 +405,60 @@ SAI2B_HD int calculate(const Input& in, int n, const double (&vmax)[MAXD], const
 		return WORKING;
 	}
 
-	// synchronize (calculator_target.hpp:120-222): candidates in stable ascending order, tried from
-	// position n-1
+	// synchronize (calculator_target.hpp:120-222): candidate durations (index q*n + d: t_min of every
+	// DoF, then the right ends of its blocked intervals) in stable ascending order, tried from
+	// position n-1; the first one no DoF blocks wins
 	int limiting = -1;
 	{
 		double cand[3 * MAXD];
 		bool any_interval = false;
-#pragma unroll
-		for (int d = 0; d < MAXD; d++) {
-			const bool on = d < n;
-			cand[d] = on ? bl[d].tmin : INFINITY;
-			cand[MAXD + d] = (on && bl[d].a) ? bl[d].aright : INFINITY;
-			cand[2 * MAXD + d] = (on && bl[d].b) ? bl[d].bright : INFINITY;
-			any_interval |= on && (bl[d].a || bl[d].b);
+#pragma unroll 1
+		for (int d = 0; d < n; d++) {
+			cand[d] = bl[d].tmin;
+			cand[n + d] = bl[d].a ? bl[d].aright : INFINITY;
+			cand[2 * n + d] = bl[d].b ? bl[d].bright : INFINITY;
+			any_interval |= bl[d].a || bl[d].b;
 		}
-		// rank of every candidate in the stable order of the reference's index array (t_min of DoF
-		// 0..n-1, then the interval ends); without intervals only the n t_min values are ranked
-		double best = INFINITY;
+		const int total = any_interval ? 3 * n : n;	 // without intervals only the n t_min values are ordered
 		int best_rank = 1 << 20, best_c = -1;
-#pragma unroll
-		for (int c = 0; c < 3 * MAXD; c++) {
-			const int cd = c % MAXD, cq = c / MAXD;
-			if (cd >= n || (!any_interval && cq > 0)) continue;
+#pragma unroll 1
+		for (int c = 0; c < total; c++) {
 			const double t = cand[c];
 			int rank = 0;
-#pragma unroll
-			for (int o = 0; o < 3 * MAXD; o++) {
-				const int od = o % MAXD, oq = o / MAXD;
-				if (od >= n || (!any_interval && oq > 0)) continue;
-				// reference index of a candidate = q * n + d
-				const bool before = (oq < cq) || (oq == cq && od < cd);
-				if (cand[o] < t || (cand[o] == t && before)) rank++;
-			}
-			if (rank < n - 1) continue;
+#pragma unroll 1
+			for (int o = 0; o < total; o++)
+				if (cand[o] < t || (cand[o] == t && o < c)) rank++;
+			if (rank < n - 1 || rank >= best_rank) continue;
 			bool blocked = false;
-#pragma unroll
-			for (int d = 0; d < MAXD; d++)
-				if (d < n && is_blocked(bl[d], t)) blocked = true;
+#pragma unroll 1
+			for (int d = 0; d < n; d++)
+				if (is_blocked(bl[d], t)) blocked = true;
 			if (blocked || t < 0.0 || isinf(t)) continue;
-			if (rank < best_rank) best_rank = rank, best = t, best_c = c;
+			best_rank = rank, best_c = c;
 		}
 		if (best_c < 0) return ERR_SYNCHRONIZATION;
-		tr.duration = best;
-		limiting = best_c % MAXD;
-		const int quot = best_c / MAXD;
-#pragma unroll
-		for (int d = 0; d < MAXD; d++)
-			if (d == limiting) tr.prof[d] = quot == 0 ? bl[d].pmin : quot == 1 ? bl[d].aprof : bl[d].bprof;
+		tr.duration = cand[best_c];
+		limiting = best_c % n;
+		const int quot = best_c / n;
+		tr.prof[limiting] = quot == 0 ? bl[limiting].pmin : quot == 1 ? bl[limiting].aprof : bl[limiting].bprof;
 	}
 
 	if (tr.duration > 7.6e3) return ERR_TRAJECTORY_DURATION;
 	if (tr.duration == 0.0) {
-#pragma unroll
-		for (int d = 0; d < MAXD; d++)
-			if (d < n) tr.prof[d] = bl[d].pmin;
+#pragma unroll 1
+		for (int d = 0; d < n; d++) tr.prof[d] = bl[d].pmin;
 		return WORKING;
 	}
 
 	// phase synchronisation (calculator_target.hpp:398-467)
 	{
-		Prof pl = tr.prof[0];
-#pragma unroll
-		for (int d = 1; d < MAXD; d++)
-			if (d == limiting) pl = tr.prof[d];
+		const Prof pl = tr.prof[limiting];
 		double npc[MAXD];
 		if (collinear(in, n, amax, pl.dir, limiting, npc)) {
 			bool found = true;
-#pragma unroll
-			for (int d = 0; d < MAXD; d++)
-				if (d < n && d != limiting) {
+#pragma unroll 1
+			for (int d = 0; d < n; d++)
+				if (d != limiting) {
 					Prof& p = tr.prof[d];
 					p.t0 = pl.t0, p.t1 = pl.t1, p.t2 = pl.t2, p.t6 = pl.t6;
 					const double aUp = npc[d], aDown = -npc[d], aMax = amax[d], aMin = -amax[d];
@@ -489,9 +472,9 @@ SAI2B_HD int calculate(const Input& in, int n, const double (&vmax)[MAXD], const
 
 	// time synchronisation (calculator_target.hpp:469-529)
 	bool bad = false;
-#pragma unroll
-	for (int d = 0; d < MAXD; d++)
-		if (d < n && d != limiting) {
+#pragma unroll 1
+	for (int d = 0; d < n; d++)
+		if (d != limiting) {
 			Prof& p = tr.prof[d];
 			const double t_profile = tr.duration - brake_duration(tr.dof[d]) - 0.0;
 			if (fabs(t_profile - bl[d].tmin) < 2 * EPS) {
@@ -575,12 +558,27 @@ SAI2B_HD bool input_differs(const Gen& g, int n, double epoch) {
 	return diff;
 }
 
+// Ruckig::update, second half (ruckig.hpp:205-215): advance along the stored trajectory
+SAI2B_HD int ruckig_sample(Gen& g, int n, double dt, int result) {
+	g.time += dt;
+#pragma unroll
+	for (int d = 0; d < MAXD; d++)
+		if (d < n) {
+			at_time(g.traj.dof[d], g.traj.prof[d], g.traj.duration, g.time, g.np[d], g.nv[d], g.na[d]);
+			g.ci.cp[d] = g.np[d], g.ci.cv[d] = g.nv[d], g.ci.ca[d] = g.na[d];
+		}
+	if (g.time > g.traj.duration) return FINISHED;
+	return result;
+}
+// does Ruckig::update have to calculate a new trajectory (ruckig.hpp:194)?
+SAI2B_HD bool needs_plan(const Gen& g, int n, double epoch) { return input_differs(g, n, epoch) || !g.ci_init; }
+
 // Ruckig::update (ruckig.hpp:180-216)
 SAI2B_HD int ruckig_update(Gen& g, int n, double dt, const double (&vmax)[MAXD], const double (&amax)[MAXD],
 						   double epoch) {
 	int result = WORKING;
 	g.replanned = 0;
-	if (input_differs(g, n, epoch) || !g.ci_init) {
+	if (needs_plan(g, n, epoch)) {
 		if (!validate(g.in, n, vmax, amax)) return ERR_INVALID_INPUT;
 		Traj tr;
 		result = calculate(g.in, n, vmax, amax, tr);
@@ -592,15 +590,7 @@ SAI2B_HD int ruckig_update(Gen& g, int n, double dt, const double (&vmax)[MAXD],
 		g.time = 0.0;
 		g.replanned = 1;
 	}
-	g.time += dt;
-#pragma unroll
-	for (int d = 0; d < MAXD; d++)
-		if (d < n) {
-			at_time(g.traj.dof[d], g.traj.prof[d], g.traj.duration, g.time, g.np[d], g.nv[d], g.na[d]);
-			g.ci.cp[d] = g.np[d], g.ci.cv[d] = g.nv[d], g.ci.ca[d] = g.na[d];
-		}
-	if (g.time > g.traj.duration) return FINISHED;
-	return result;
+	return ruckig_sample(g, n, dt, result);
 }
 
 SAI2B_HD void pass_to_input(Gen& g, int n) {
@@ -639,22 +629,33 @@ SAI2B_HD void joints_reinitialize(Gen& g, int n, const double (&x0)[MAXD]) {
 		if (d < n) g.np[d] = x0[d], g.nv[d] = 0, g.na[d] = 0;
 	pass_to_input(g, n);
 }
-// OTG_joints::update (OTG_joints.cpp:118-150). The Finished-with-velocity branch calls
-// setGoalPosition with a member that is never assigned (:129), which throws in the reference; it
-// does what the Cartesian wrapper does there (keep the target position, zero the target velocity).
-SAI2B_HD void joints_update(Gen& g, int n, double dt, const double (&vmax)[MAXD], const double (&amax)[MAXD],
-							double epoch) {
-	if (g.goal_reached) return;
-	double pp[MAXD], pv[MAXD], pa[MAXD];
+// `previous_output` of the wrappers' update() (OTG_joints.cpp:123, OTG_6dof_cartesian.cpp:192)
+struct Prev {
+	double p[MAXD], v[MAXD], a[MAXD];
+};
+SAI2B_HD void save_prev(const Gen& g, Prev& pv) {
 #pragma unroll
-	for (int d = 0; d < MAXD; d++) pp[d] = g.np[d], pv[d] = g.nv[d], pa[d] = g.na[d];
-	g.result = ruckig_update(g, n, dt, vmax, amax, epoch);
+	for (int d = 0; d < MAXD; d++) pv.p[d] = g.np[d], pv.v[d] = g.nv[d], pv.a[d] = g.na[d];
+}
+SAI2B_HD void on_error(Gen& g, int n, const Prev& pv) {	 // OTG_joints.cpp:141-149, OTG_6dof_cartesian.cpp:215-223
+#pragma unroll
+	for (int d = 0; d < MAXD; d++)
+		if (d < n) g.np[d] = pv.p[d], g.nv[d] = pv.v[d], g.na[d] = pv.a[d], g.in.cv[d] = 0, g.in.ca[d] = 0;
+}
+SAI2B_HD double velocity_norm(const Gen& g, int n) {
+	double nrm = 0;
+#pragma unroll
+	for (int d = 0; d < MAXD; d++)
+		if (d < n) nrm += g.nv[d] * g.nv[d];
+	return sqrt(nrm);
+}
+// OTG_joints::update after _otg->update() returned g.result (OTG_joints.cpp:125-149). The
+// Finished-with-velocity branch calls setGoalPosition with a member that is never assigned (:129),
+// which throws in the reference; it does what the Cartesian wrapper does there (keep the target
+// position, zero the target velocity).
+SAI2B_HD void joints_finish(Gen& g, int n, const Prev& pv) {
 	if (g.result == FINISHED) {
-		double nrm = 0;
-#pragma unroll
-		for (int d = 0; d < MAXD; d++)
-			if (d < n) nrm += g.nv[d] * g.nv[d];
-		if (sqrt(nrm) < 1e-3) {
+		if (velocity_norm(g, n) < 1e-3) {
 			g.goal_reached = 1;
 		} else {
 			const double zeros[MAXD] = {0, 0, 0, 0, 0, 0, 0};
@@ -663,15 +664,20 @@ SAI2B_HD void joints_update(Gen& g, int n, double dt, const double (&vmax)[MAXD]
 			for (int d = 0; d < MAXD; d++) tp[d] = g.in.tp[d];
 			joints_set_goal(g, n, tp, zeros);
 		}
-		return;
-	}
-	if (g.result == WORKING) {
+	} else if (g.result == WORKING) {
 		pass_to_input(g, n);
-		return;
+	} else {
+		on_error(g, n, pv);
 	}
-#pragma unroll
-	for (int d = 0; d < MAXD; d++)
-		if (d < n) g.np[d] = pp[d], g.nv[d] = pv[d], g.na[d] = pa[d], g.in.cv[d] = 0, g.in.ca[d] = 0;
+}
+// OTG_joints::update (OTG_joints.cpp:118-150)
+SAI2B_HD void joints_update(Gen& g, int n, double dt, const double (&vmax)[MAXD], const double (&amax)[MAXD],
+							double epoch) {
+	if (g.goal_reached) return;
+	Prev pv;
+	save_prev(g, pv);
+	g.result = ruckig_update(g, n, dt, vmax, amax, epoch);
+	joints_finish(g, n, pv);
 }
 
 // ---- rotations (Eigen AngleAxisd semantics, from the published algorithms) ----
@@ -809,18 +815,10 @@ SAI2B_HD void cart_reinitialize(Gen& g, const double* pos, const double* rot) {
 		g.np[i] = g.in.tp[i], g.nv[i] = 0, g.na[i] = 0;
 	}
 }
-// OTG_6dof_cartesian::update (OTG_6dof_cartesian.cpp:187-224)
-SAI2B_HD void cart_update(Gen& g, double dt, const double (&vmax)[MAXD], const double (&amax)[MAXD], double epoch) {
-	if (g.goal_reached) return;
-	double pp[6], pv[6], pa[6];
-#pragma unroll
-	for (int d = 0; d < 6; d++) pp[d] = g.np[d], pv[d] = g.nv[d], pa[d] = g.na[d];
-	g.result = ruckig_update(g, 6, dt, vmax, amax, epoch);
+// OTG_6dof_cartesian::update after _otg->update() returned g.result (OTG_6dof_cartesian.cpp:194-223)
+SAI2B_HD void cart_finish(Gen& g, const Prev& pv) {
 	if (g.result == FINISHED) {
-		double nrm = 0;
-#pragma unroll
-		for (int d = 0; d < 6; d++) nrm += g.nv[d] * g.nv[d];
-		if (sqrt(nrm) < 1e-3) {
+		if (velocity_norm(g, 6) < 1e-3) {
 			g.goal_reached = 1;
 		} else {
 			const double zeros[3] = {0, 0, 0};
@@ -831,14 +829,19 @@ SAI2B_HD void cart_update(Gen& g, double dt, const double (&vmax)[MAXD], const d
 			cart_set_goal_position(g, tp, zeros);
 			cart_set_goal_orientation(g, gR, zeros);
 		}
-		return;
-	}
-	if (g.result == WORKING) {
+	} else if (g.result == WORKING) {
 		pass_to_input(g, 6);
-		return;
+	} else {
+		on_error(g, 6, pv);
 	}
-#pragma unroll
-	for (int d = 0; d < 6; d++) g.np[d] = pp[d], g.nv[d] = pv[d], g.na[d] = pa[d], g.in.cv[d] = 0, g.in.ca[d] = 0;
+}
+// OTG_6dof_cartesian::update (OTG_6dof_cartesian.cpp:187-224)
+SAI2B_HD void cart_update(Gen& g, double dt, const double (&vmax)[MAXD], const double (&amax)[MAXD], double epoch) {
+	if (g.goal_reached) return;
+	Prev pv;
+	save_prev(g, pv);
+	g.result = ruckig_update(g, 6, dt, vmax, amax, epoch);
+	cart_finish(g, pv);
 }
 
 }  // namespace otg
