@@ -7,7 +7,8 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it; the product
  * (sai2-primitives-perso_amd/) never links, imports or calls anything in this directory.
  *
- * PARITY STATUS: "parity unpinned" at the sai2-model / Eigen boundary. The reference cannot be
+ * PARITY STATUS: "parity unpinned" at the sai2-model / Eigen boundary (the internal OTG's planner is
+ * the exception: otg_oracle.h, pinned against the reference's own ruckig core in oracle/_ref). The reference cannot be
  * compiled here (Eigen3 and sai2-model are absent, no network: SURVEY.md §8(c)) and ships no
  * tests, fixtures or golden vectors for src/. The oracle is pinned instead by
  *   (1) an independent numpy/float64 restatement (tests/golden/make_golden.py) whose outputs are
