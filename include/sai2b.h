@@ -249,6 +249,22 @@ int sai2b_get_mft_singularity(sai2b_ctx* ctx, int task, double* sigma, double* a
  * MotionForceTask::getUnitMassForce and the observers of POPCBilateralTeleoperation.cpp:81-92,172-182
  * read (MotionForceTask.cpp:478-487) */
 int sai2b_get_mft_task_forces(sai2b_ctx* ctx, int task, double* F_unit, double* F_force);
+/* ------------------------------------------------------------------ simulation harness
+ * What the reference's examples obtain from the external sai2-simulation (examples/05-...cpp:215-236:
+ * setJointTorques / integrate / getJointPositions, getJointVelocities): one control period of
+ * rigid-body dynamics  M qdd + C dq (+ g) = tau  for every robot, with the state staying in device
+ * memory between ticks. tau [7][B] (host, or device when on_device != 0; NULL = the torques of the
+ * last sai2b_compute_control_torques / sai2b_tick) is held over dt, which is split into `substeps`
+ * semi-implicit Euler steps. with_gravity uses sai2b_robot_model.gravity (the example worlds have
+ * none). The state buffers (SAI2B_BUF_Q / SAI2B_BUF_DQ) are updated in place. */
+int sai2b_sim_step(sai2b_ctx* ctx, const double* tau, int on_device, double dt, int substeps,
+				   int with_gravity);
+/* current joint positions / velocities to host arrays [7][B] (either may be NULL) */
+int sai2b_get_state(sai2b_ctx* ctx, double* q, double* dq);
+/* bias vector C(q, dq) dq (+ g(q)) of the current state, host [7][B] (Sai2Model::coriolisForce /
+ * jointGravityVector of sai2-model) */
+int sai2b_get_bias(sai2b_ctx* ctx, int with_gravity, double* bias);
+
 /* Desired state the control law tracked in the last torque computation: the goal, or with the
  * internal OTG on its next state (JointTask::getDesiredPosition/Velocity/Acceleration,
  * JointTask.h:182-198; MotionForceTask::getDesired*). Host arrays, SoA [rows][B]; any may be NULL.

@@ -643,6 +643,81 @@ static void gravity_vector(const oracle_ctx* c, const robot_t* r, double* g) {
 			for (int d = 0; d < 3; d++) g[i] -= c->model.link_mass[k] * J[d * N7 + i] * c->model.gravity[d];
 	}
 }
+/* ---- simulation harness: rigid-body forward dynamics. The reference's examples get
+ * this from the external sai2-simulation (examples/05-...cpp:215-236); nothing of it is in the
+ * reference tree, so these are textbook definitions of ours. ----
+ * b(q, dq) = C(q, dq) dq (+ g(q)): recursive Newton-Euler with qdd = 0, world-frame quantities. */
+static void bias_vector(const oracle_ctx* c, const robot_t* r, int with_gravity, double* b) {
+	double w[N7][3], al[N7][3], F[N7][3], Nn[N7][3], cw[N7][3];
+	double w_prev[3] = {0, 0, 0}, al_prev[3] = {0, 0, 0}, a_prev[3] = {0, 0, 0}, o_prev[3] = {0, 0, 0};
+	if (with_gravity)
+		for (int k = 0; k < 3; k++) a_prev[k] = -c->model.gravity[k];
+	for (int i = 0; i < N7; i++) {
+		const double* R = r->Rl[i];
+		const double z[3] = {R[2], R[5], R[8]};
+		double rr[3], t1[3], t2[3], a_i[3], zq[3];
+		for (int k = 0; k < 3; k++) rr[k] = r->pl[i][k] - o_prev[k];
+		cross3(al_prev, rr, t1);
+		cross3(w_prev, rr, t2);
+		double t3[3];
+		cross3(w_prev, t2, t3);
+		for (int k = 0; k < 3; k++) a_i[k] = a_prev[k] + t1[k] + t3[k];
+		for (int k = 0; k < 3; k++) zq[k] = z[k] * r->dq[i];
+		cross3(w_prev, zq, t1);
+		for (int k = 0; k < 3; k++) {
+			w[i][k] = w_prev[k] + zq[k];
+			al[i][k] = al_prev[k] + t1[k];
+		}
+		double rc[3];
+		for (int k = 0; k < 3; k++) {
+			rc[k] = R[3 * k] * c->model.link_com[i][0] + R[3 * k + 1] * c->model.link_com[i][1] +
+					R[3 * k + 2] * c->model.link_com[i][2];
+			cw[i][k] = r->pl[i][k] + rc[k];
+		}
+		double a_c[3];
+		cross3(al[i], rc, t1);
+		cross3(w[i], rc, t2);
+		cross3(w[i], t2, t3);
+		for (int k = 0; k < 3; k++) a_c[k] = a_i[k] + t1[k] + t3[k];
+		const double* li = c->model.link_inertia[i];
+		double Il[9] = {li[0], li[3], li[4], li[3], li[1], li[5], li[4], li[5], li[2]}, T[9], Iw[9];
+		mm(3, 3, 3, R, Il, T);
+		mm_nt(3, 3, 3, T, R, Iw);
+		double Ial[3], Iom[3];
+		mm(3, 3, 1, Iw, al[i], Ial);
+		mm(3, 3, 1, Iw, w[i], Iom);
+		cross3(w[i], Iom, t1);
+		for (int k = 0; k < 3; k++) {
+			F[i][k] = c->model.link_mass[i] * a_c[k];
+			Nn[i][k] = Ial[k] + t1[k];
+			w_prev[k] = w[i][k];
+			al_prev[k] = al[i][k];
+			a_prev[k] = a_i[k];
+			o_prev[k] = r->pl[i][k];
+		}
+	}
+	double f_next[3] = {0, 0, 0}, n_next[3] = {0, 0, 0};
+	for (int i = N7 - 1; i >= 0; i--) {
+		double f[3], n[3], d[3], t1[3];
+		for (int k = 0; k < 3; k++) d[k] = cw[i][k] - r->pl[i][k];
+		cross3(d, F[i], t1);
+		for (int k = 0; k < 3; k++) {
+			f[k] = F[i][k] + f_next[k];
+			n[k] = Nn[i][k] + n_next[k] + t1[k];
+		}
+		if (i + 1 < N7) {
+			for (int k = 0; k < 3; k++) d[k] = r->pl[i + 1][k] - r->pl[i][k];
+			cross3(d, f_next, t1);
+			for (int k = 0; k < 3; k++) n[k] += t1[k];
+		}
+		b[i] = r->Rl[i][2] * n[0] + r->Rl[i][5] * n[1] + r->Rl[i][8] * n[2];
+		for (int k = 0; k < 3; k++) {
+			f_next[k] = f[k];
+			n_next[k] = n[k];
+		}
+	}
+}
+
 static void frame_pose(const sai2b_task_config* t, const double Rl[N7][9], const double pl[N7][3], double* x,
 					   double* R) {
 	for (int k = 0; k < 3; k++)
@@ -1626,6 +1701,47 @@ int oracle_get_mft_task_forces(oracle_ctx* c, int task, double* Fu, double* Ff) 
 			if (Fu) Fu[i * c->B + b] = c->mft[task][b].Fu[i];
 			if (Ff) Ff[i * c->B + b] = c->mft[task][b].Ff[i];
 		}
+	return 0;
+}
+/* one control period of the simulated robots: tau ([7][B], NULL = zero) held over dt, `substeps`
+ * semi-implicit Euler steps dq += h M^-1 (tau - b), q += h dq */
+int oracle_sim_step(oracle_ctx* c, const double* tau, double dt, int substeps, int with_gravity) {
+	if (!c || substeps < 1 || !(dt > 0)) return fail("oracle_sim_step: bad arguments");
+	const double h = dt / substeps;
+#pragma omp parallel for num_threads(c->threads) schedule(static)
+	for (int b = 0; b < c->B; b++) {
+		robot_t* r = &c->robots[b];
+		for (int s = 0; s < substeps; s++) {
+			update_model(c, r);
+			double bias[N7], rhs[N7], qdd[N7];
+			bias_vector(c, r, with_gravity, bias);
+			for (int i = 0; i < N7; i++) rhs[i] = (tau ? tau[i * c->B + b] : 0.0) - bias[i];
+			mm(N7, N7, 1, r->Minv, rhs, qdd);
+			for (int i = 0; i < N7; i++) {
+				r->dq[i] += h * qdd[i];
+				r->q[i] += h * r->dq[i];
+			}
+		}
+		r->model_valid = 0;
+	}
+	return 0;
+}
+int oracle_get_state(oracle_ctx* c, double* q, double* dq) {
+	for (int b = 0; b < c->B; b++)
+		for (int i = 0; i < N7; i++) {
+			if (q) q[i * c->B + b] = c->robots[b].q[i];
+			if (dq) dq[i * c->B + b] = c->robots[b].dq[i];
+		}
+	return 0;
+}
+/* bias vector C dq (+ g) [7][B] at the current state */
+int oracle_get_bias(oracle_ctx* c, int with_gravity, double* out) {
+	for (int b = 0; b < c->B; b++) {
+		ensure_model(c, b);
+		double g[N7];
+		bias_vector(c, &c->robots[b], with_gravity, g);
+		for (int i = 0; i < N7; i++) out[i * c->B + b] = g[i];
+	}
 	return 0;
 }
 int oracle_get_jt_desired(oracle_ctx* c, int task, double* q, double* dq, double* ddq) {

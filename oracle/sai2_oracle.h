@@ -81,6 +81,13 @@ int oracle_get_mft_lambda(oracle_ctx* ctx, int task, double* Lambda_ns_full,
 						  double* Lambda_ns_mod_full);
 /* MFT: F_unit and F_force of the last computeTorques, [6][B] each */
 int oracle_get_mft_task_forces(oracle_ctx* ctx, int task, double* F_unit, double* F_force);
+/* simulation harness (the reference uses the external sai2-simulation,
+ * examples/05-...cpp:215-236, so these are definitions of ours): advance every robot by one control
+ * period dt under joint torques tau ([7][B], NULL = zero) held constant, with `substeps`
+ * semi-implicit Euler steps of the rigid-body dynamics M qdd + C dq (+ g) = tau */
+int oracle_sim_step(oracle_ctx* ctx, const double* tau, double dt, int substeps, int with_gravity);
+int oracle_get_state(oracle_ctx* ctx, double* q, double* dq);
+int oracle_get_bias(oracle_ctx* ctx, int with_gravity, double* bias);
 /* desired state of the last computeTorques = goal, or the internal OTG's next state
  * (JointTask.h:182-198 getDesired*, MotionForceTask.h getDesired*); any pointer may be NULL */
 int oracle_get_jt_desired(oracle_ctx* ctx, int task, double* q, double* dq, double* ddq);

@@ -179,6 +179,9 @@ EXPORTS = [
     "sai2b_get_task_torques",
     "sai2b_get_mft_singularity",
     "sai2b_get_mft_task_forces",
+    "sai2b_sim_step",
+    "sai2b_get_state",
+    "sai2b_get_bias",
     "sai2b_get_jt_desired",
     "sai2b_get_mft_desired",
     "sai2b_get_otg_status",
@@ -246,6 +249,9 @@ def load_library():
     lib.sai2b_get_task_torques.argtypes = [vp, _i, vp]
     lib.sai2b_get_mft_singularity.argtypes = [vp, _i, vp, vp, vp]
     lib.sai2b_get_mft_task_forces.argtypes = [vp, _i, vp, vp]
+    lib.sai2b_sim_step.argtypes = [vp, vp, _i, _d, _i, _i]
+    lib.sai2b_get_state.argtypes = [vp, vp, vp]
+    lib.sai2b_get_bias.argtypes = [vp, _i, vp]
     lib.sai2b_get_jt_desired.argtypes = [vp, _i, vp, vp, vp]
     lib.sai2b_get_mft_desired.argtypes = [vp, _i, vp, vp, vp, vp, vp, vp]
     lib.sai2b_get_otg_status.argtypes = [vp, _i, vp, vp]

@@ -251,6 +251,23 @@ class Controller:
         self._rc(self.lib.sai2b_get_mft_task_forces(self.h, task, C.c_void_p(fu.ctypes.data), C.c_void_p(ff.ctypes.data)))
         return fu, ff
 
+    # -- simulation harness
+    def sim_step(self, tau=None, dt=0.001, substeps=1, with_gravity=False):
+        """one control period of rigid-body dynamics under `tau` (None = the last computed torques; numpy
+        [7][B] or a torch CUDA tensor), state updated in place on the device"""
+        p, _ = self._in(tau, DOF)
+        self._rc(self.lib.sai2b_sim_step(self.h, p, self._dev(tau), float(dt), int(substeps), int(with_gravity)))
+
+    def get_state(self):
+        q, dq = np.empty((DOF, self.B)), np.empty((DOF, self.B))
+        self._rc(self.lib.sai2b_get_state(self.h, C.c_void_p(q.ctypes.data), C.c_void_p(dq.ctypes.data)))
+        return q, dq
+
+    def get_bias(self, with_gravity=False):
+        out = np.empty((DOF, self.B))
+        self._rc(self.lib.sai2b_get_bias(self.h, int(with_gravity), C.c_void_p(out.ctypes.data)))
+        return out
+
     def get_jt_desired(self, task):
         """desired q, dq, ddq of a JointTask: the goal, or the internal OTG's next state"""
         k0 = self.tasks[task].task_dof

@@ -41,6 +41,7 @@ struct sai2b_ctx {
 	DevParams* d_params = nullptr;
 	hipStream_t stream = nullptr;
 	double *q = nullptr, *dq = nullptr, *tau = nullptr;
+	double* sim_tau = nullptr;	// staging for host torques / bias read-back of the simulation harness
 	std::vector<void*> allocs;
 	long long launches = 0, ticks = 0;
 	std::string error;
@@ -903,6 +904,46 @@ static int fetch_rows(sai2b_ctx* ctx, const double* src, size_t row0, size_t row
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return SAI2B_OK;
 }
+// ---- simulation harness ----
+extern "C" int sai2b_sim_step(sai2b_ctx* ctx, const double* tau, int on_device, double dt, int substeps, int with_gravity) {
+	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	if (!(dt > 0) || substeps < 1 || substeps > 1000) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_sim_step: dt must be > 0 and substeps in [1, 1000]");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	int rc = upload_params(ctx);
+	if (rc) return rc;
+	const double* t = ctx->tau;	 // default: the torques of the last computeControlTorques
+	if (tau && on_device) {
+		t = tau;
+	} else if (tau) {
+		if (!ctx->sim_tau && (rc = dev_alloc(ctx, &ctx->sim_tau, (size_t)N * ctx->B))) return rc;
+		if ((rc = copy_rows(ctx, ctx->sim_tau, tau, N, 0))) return rc;
+		t = ctx->sim_tau;
+	}
+	if (sai2b_launch_sim(ctx->d_params, ctx->B, t, dt, substeps, with_gravity, nullptr, ctx->stream))
+		return set_error(ctx, SAI2B_RUNTIME_ERROR, "simulation launch failed");
+	ctx->launches++;
+	ctx->models_fresh = false;
+	return SAI2B_OK;
+}
+extern "C" int sai2b_get_state(sai2b_ctx* ctx, double* q, double* dq) {
+	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	int rc = fetch_rows(ctx, ctx->q, 0, N, q);
+	if (rc) return rc;
+	return fetch_rows(ctx, ctx->dq, 0, N, dq);
+}
+extern "C" int sai2b_get_bias(sai2b_ctx* ctx, int with_gravity, double* bias) {
+	if (!ctx || !bias) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_get_bias: bad arguments");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	int rc = upload_params(ctx);
+	if (rc) return rc;
+	if (!ctx->sim_tau && (rc = dev_alloc(ctx, &ctx->sim_tau, (size_t)N * ctx->B))) return rc;
+	// a zero-length step leaves the state as it is and writes the bias vector of the current state
+	if (sai2b_launch_sim(ctx->d_params, ctx->B, nullptr, 0.0, 1, with_gravity, ctx->sim_tau, ctx->stream))
+		return set_error(ctx, SAI2B_RUNTIME_ERROR, "simulation launch failed");
+	return fetch_rows(ctx, ctx->sim_tau, 0, N, bias);
+}
+
 extern "C" int sai2b_get_jt_desired(sai2b_ctx* ctx, int task, double* q, double* dq, double* ddq) {
 	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
 	if (task < 0 || task >= ctx->T || ctx->cfg[task].type != SAI2B_JOINT_TASK)

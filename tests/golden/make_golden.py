@@ -120,6 +120,55 @@ def rnea(q, qdd, a0):
     return tau
 
 
+def rnea_full(q, dq, qdd, a0):
+    """inverse dynamics tau = M qdd + C(q, dq) dq + (gravity term for base acceleration a0), recursive
+    Newton-Euler with every quantity in the world frame"""
+    R, p = fk(q)
+    w_prev, al_prev, a_prev, o_prev = np.zeros(3), np.zeros(3), a0.copy(), np.zeros(3)
+    F, Nn, cw = [], [], []
+    for i in range(N):
+        z = R[i][:, 2]
+        r = p[i] - o_prev
+        a_i = a_prev + np.cross(al_prev, r) + np.cross(w_prev, np.cross(w_prev, r))
+        w_i = w_prev + z * dq[i]
+        al_i = al_prev + z * qdd[i] + np.cross(w_prev, z * dq[i])
+        c = p[i] + R[i] @ LC[i]
+        rc = c - p[i]
+        a_c = a_i + np.cross(al_i, rc) + np.cross(w_i, np.cross(w_i, rc))
+        Iw = R[i] @ LI[i] @ R[i].T
+        F.append(LM[i] * a_c)
+        Nn.append(Iw @ al_i + np.cross(w_i, Iw @ w_i))
+        cw.append(c)
+        w_prev, al_prev, a_prev, o_prev = w_i, al_i, a_i, p[i]
+    tau = np.zeros(N)
+    f_next, n_next = np.zeros(3), np.zeros(3)
+    for i in reversed(range(N)):
+        f = F[i] + f_next
+        n = Nn[i] + n_next + np.cross(cw[i] - p[i], F[i])
+        if i + 1 < N:
+            n = n + np.cross(p[i + 1] - p[i], f_next)
+        tau[i] = R[i][:, 2] @ n
+        f_next, n_next = f, n
+    return tau
+
+
+def bias_vector(q, dq, with_gravity=False):
+    """b(q, dq) = C dq (+ g): what forward dynamics subtracts from the torques"""
+    return rnea_full(q, dq, np.zeros(N), -GRAVITY if with_gravity else np.zeros(3))
+
+
+def sim_step(q, dq, tau, dt, substeps=1, with_gravity=False):
+    """the simulation harness' integrator: tau held over the step, semi-implicit Euler sub-steps
+    dq += h M^-1 (tau - b), q += h dq"""
+    h = dt / substeps
+    q, dq = q.copy(), dq.copy()
+    for _ in range(substeps):
+        qdd = np.linalg.solve(mass_matrix(q), tau - bias_vector(q, dq, with_gravity))
+        dq = dq + h * qdd
+        q = q + h * dq
+    return q, dq
+
+
 def mass_matrix(q):
     M = np.zeros((N, N))
     for i in range(N):

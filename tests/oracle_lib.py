@@ -64,6 +64,9 @@ def lib():
     L.oracle_get_jt_desired.argtypes = [vp, i, vp, vp, vp]
     L.oracle_get_mft_desired.argtypes = [vp, i] + [vp] * 6
     L.oracle_get_otg_status.argtypes = [vp, i, vp, vp]
+    L.oracle_sim_step.argtypes = [vp, vp, d, i, i]
+    L.oracle_get_state.argtypes = [vp, vp, vp]
+    L.oracle_get_bias.argtypes = [vp, i, vp]
     L.oracle_svd.argtypes = [i, i, vp, vp, vp, vp]
     L.oracle_svd.restype = None
     L.oracle_inverse.argtypes = [i, vp, vp]
@@ -279,6 +282,20 @@ class Oracle:
         assert self.L.oracle_get_jt_inertia(self.h, task, _ptr(a), _ptr(b)) == 0
         return a, b
 
+
+    def sim_step(self, tau, dt=0.001, substeps=1, with_gravity=False):
+        tau = _arr(tau, (DOF, self.B))
+        assert self.L.oracle_sim_step(self.h, _ptr(tau), dt, substeps, int(with_gravity)) == 0
+
+    def get_state(self):
+        q, dq = np.empty((DOF, self.B)), np.empty((DOF, self.B))
+        self.L.oracle_get_state(self.h, _ptr(q), _ptr(dq))
+        return q, dq
+
+    def get_bias(self, with_gravity=False):
+        out = np.empty((DOF, self.B))
+        self.L.oracle_get_bias(self.h, int(with_gravity), _ptr(out))
+        return out
 
     def get_jt_desired(self, task):
         k0 = self._k0(task)
