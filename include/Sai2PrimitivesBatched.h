@@ -466,6 +466,34 @@ inline Batch MotionForceTask::getSigmaValues() const {
 	detail::check(_owner->ctx(), sai2b_get_mft_singularity(_owner->ctx(), _index, out.data(), nullptr, nullptr));
 	return out;
 }
+// Stands in for Sai2Simulation in the examples' loops (examples/05-...cpp:215-236: setJointTorques,
+// integrate, getJointPositions, getJointVelocities): rigid-body dynamics of the whole batch with the
+// state resident on the device (sai2b_sim_step). Without setJointTorques, integrate() consumes the
+// torques of the controller's last computeControlTorques() without a host round trip.
+class BatchedSimulation {
+public:
+	explicit BatchedSimulation(RobotController& controller, const double timestep = 0.001, const int substeps = 1)
+		: _controller(controller), _dt(timestep), _substeps(substeps) {
+		if (timestep <= 0 || substeps < 1) throw std::invalid_argument("simulation timestep must be positive");
+	}
+	void setTimestep(const double dt) {
+		if (dt <= 0) throw std::invalid_argument("simulation timestep must be positive");
+		_dt = dt;
+	}
+	void enableGravity(const bool on = true) { _gravity = on; }
+	void setJointTorques(const Batch& tau) { _tau = tau; }
+	inline void integrate();
+	inline Batch getJointPositions() const;
+	inline Batch getJointVelocities() const;
+
+private:
+	RobotController& _controller;
+	double _dt;
+	int _substeps;
+	bool _gravity = false;
+	Batch _tau;
+};
+
 inline Batch JointTask::desired(int which) const {
 	if (!_owner) throw std::invalid_argument("task is not attached to a RobotController");
 	Batch out((size_t)_cfg.task_dof * B());
@@ -491,6 +519,22 @@ inline Batch MotionForceTask::getDesiredLinearVelocity() const { return desired(
 inline Batch MotionForceTask::getDesiredAngularVelocity() const { return desired(3); }
 inline Batch MotionForceTask::getDesiredLinearAcceleration() const { return desired(4); }
 inline Batch MotionForceTask::getDesiredAngularAcceleration() const { return desired(5); }
+inline void BatchedSimulation::integrate() {
+	sai2b_ctx* c = _controller.ctx();
+	if (!_tau.empty() && _tau.size() != 7 * (size_t)sai2b_batch(c)) throw std::invalid_argument("joint torques must have shape [7][B]");
+	detail::check(c, sai2b_sim_step(c, _tau.empty() ? nullptr : _tau.data(), 0, _dt, _substeps, _gravity ? 1 : 0));
+	_tau.clear();
+}
+inline Batch BatchedSimulation::getJointPositions() const {
+	Batch q(7 * (size_t)sai2b_batch(_controller.ctx()));
+	detail::check(_controller.ctx(), sai2b_get_state(_controller.ctx(), q.data(), nullptr));
+	return q;
+}
+inline Batch BatchedSimulation::getJointVelocities() const {
+	Batch dq(7 * (size_t)sai2b_batch(_controller.ctx()));
+	detail::check(_controller.ctx(), sai2b_get_state(_controller.ctx(), nullptr, dq.data()));
+	return dq;
+}
 inline void JointTask::flushGoals() {
 	if (!_owner) return;
 	auto p = [](const Batch& b) { return b.empty() ? nullptr : b.data(); };

@@ -16,6 +16,7 @@ from ._abi import (  # noqa: F401
 )
 from .controller import (  # noqa: F401,E402
     BatchedRobotModel,
+    BatchedSimulation,
     Controller,
     JointTask,
     MotionForceTask,

@@ -721,3 +721,35 @@ class RobotController:
 
     def getMotionForceTaskByName(self, name):
         return self._by_name(name, MOTION_FORCE_TASK, "MotionForceTask")
+
+
+class BatchedSimulation:
+    """Stands in for Sai2Simulation in the examples' loops (examples/05-...cpp:215-236): rigid-body dynamics
+    of the batch, state resident on the device. Without setJointTorques, integrate() consumes the torques
+    of the controller's last computeControlTorques() / tick() without a host round trip."""
+
+    def __init__(self, controller, timestep=0.001, substeps=1):
+        if timestep <= 0 or substeps < 1:
+            raise ValueError("simulation timestep must be positive")
+        self._c, self._dt, self._substeps, self._gravity, self._tau = controller, float(timestep), int(substeps), False, None
+
+    def setTimestep(self, dt):
+        if dt <= 0:
+            raise ValueError("simulation timestep must be positive")
+        self._dt = float(dt)
+
+    def enableGravity(self, on=True):
+        self._gravity = bool(on)
+
+    def setJointTorques(self, tau):
+        self._tau = tau
+
+    def integrate(self):
+        self._c._ctrl.sim_step(self._tau, self._dt, self._substeps, self._gravity)
+        self._tau = None
+
+    def getJointPositions(self):
+        return self._c._ctrl.get_state()[0]
+
+    def getJointVelocities(self):
+        return self._c._ctrl.get_state()[1]

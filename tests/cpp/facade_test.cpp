@@ -99,6 +99,12 @@ static int tick(int B, const char* path) {
 	ctl.updateControllerTaskModels();
 	Batch tau = ctl.computeControlTorques();
 	std::fwrite(tau.data(), sizeof(double), tau.size(), stdout);
+	// the examples' simulation step (examples/05-...cpp:215-236), state staying on the device
+	BatchedSimulation sim(ctl, 0.001, 2);
+	sim.integrate();
+	Batch q1 = sim.getJointPositions(), dq1 = sim.getJointVelocities();
+	std::fwrite(q1.data(), sizeof(double), q1.size(), stdout);
+	std::fwrite(dq1.data(), sizeof(double), dq1.size(), stdout);
 	return 0;
 }
 

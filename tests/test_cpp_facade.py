@@ -43,8 +43,13 @@ def test_cpp_facade_tick_matches_oracle(facade_bin, tmp_path):
     blob.astype(np.float64).tofile(path)
     r = subprocess.run([facade_bin, "tick", str(B), str(path)], capture_output=True)
     assert r.returncode == 0, r.stderr.decode()
-    tau = np.frombuffer(r.stdout, dtype=np.float64).reshape(7, B)
+    out = np.frombuffer(r.stdout, dtype=np.float64).reshape(3, 7, B)
+    tau, q1, dq1 = out
     o = ol.Oracle(ol.panda_model(), ol.task_configs(inp["tasks"]), B)
     ol.load_inputs(o, inp)
     ref = o.tick()
     assert (np.abs(tau - ref).max(axis=0) / np.maximum(np.abs(ref).max(axis=0), 1)).max() < 1e-10
+    # BatchedSimulation::integrate() consumed those torques on the device (2 sub-steps of 0.5 ms)
+    o.sim_step(ref, 0.001, substeps=2)
+    qo, vo = o.get_state()
+    assert np.abs(q1 - qo).max() < 1e-12 and np.abs(dq1 - vo).max() < 1e-10
