@@ -62,6 +62,20 @@ public:
 		detail::check(nullptr, sai2b_panda_model(&_model));
 	}
 	BatchedRobotModel(int batch, const sai2b_robot_model& model, int device = 0) : BatchedRobotModel(batch, device) { _model = model; }
+	// Sai2Model::Sai2Model(urdf_file) (examples/05-...cpp:96-97): the robot description from a URDF file
+	BatchedRobotModel(const std::string& urdf_file, int batch, int device = 0) : BatchedRobotModel(batch, device) {
+		detail::check(nullptr, sai2b_model_from_urdf(urdf_file.c_str(), 1, &_model, &_links));
+		_has_links = true;
+	}
+	// link name + compliant frame in that link (what the reference's task constructors take) -> moving link
+	// index and frame in it; the name may be a body behind fixed joints, e.g. "end-effector"
+	int resolveLink(const std::string& link_name, const double pos_in_link[3], const double* rot_in_link, double frame_pos[3],
+					double frame_rot[9]) const {
+		if (!_has_links) throw std::invalid_argument("link names need a robot model built from a URDF file");
+		int link = -1;
+		detail::check(nullptr, sai2b_urdf_resolve_frame(&_links, link_name.c_str(), pos_in_link, rot_in_link, &link, frame_pos, frame_rot));
+		return link;
+	}
 	int dof() const { return SAI2B_DOF; }
 	int batch() const { return _batch; }
 	int device() const { return _device; }
@@ -82,6 +96,8 @@ private:
 	}
 	int _batch, _device;
 	sai2b_robot_model _model;
+	sai2b_urdf_links _links;
+	bool _has_links = false;
 	Batch _q, _dq;
 	RobotController* _controller = nullptr;
 };
@@ -218,6 +234,17 @@ public:
 		: TemplateTask(robot, MOTION_FORCE_TASK) {
 		detail::check(nullptr, sai2b_default_motion_force_task(&_cfg, task_name.c_str(), link, compliant_frame_pos, compliant_frame_rot, -1,
 															   nullptr, -1, nullptr));
+		_cfg.parametrization_in_compliant_frame = is_force_motion_parametrization_in_compliant_frame;
+		_cfg.loop_timestep = loop_timestep;
+	}
+	// MotionForceTask.h:96-101 with the link given by NAME, as in the reference (robot built from a URDF file)
+	MotionForceTask(std::shared_ptr<BatchedRobotModel>& robot, const std::string& link_name, const double compliant_frame_pos[3],
+					const double* compliant_frame_rot = nullptr, const std::string& task_name = "motion_force_task",
+					const bool is_force_motion_parametrization_in_compliant_frame = false, const double loop_timestep = 0.001)
+		: TemplateTask(robot, MOTION_FORCE_TASK) {
+		double fp[3], fr[9];
+		const int link = robot->resolveLink(link_name, compliant_frame_pos, compliant_frame_rot, fp, fr);
+		detail::check(nullptr, sai2b_default_motion_force_task(&_cfg, task_name.c_str(), link, fp, fr, -1, nullptr, -1, nullptr));
 		_cfg.parametrization_in_compliant_frame = is_force_motion_parametrization_in_compliant_frame;
 		_cfg.loop_timestep = loop_timestep;
 	}

@@ -140,6 +140,30 @@ int sai2b_model_merge_fixed_body(sai2b_robot_model* model, int link, const doubl
 								 const double rpy[3], double mass, const double com[3],
 								 const double inertia[6]);
 
+/* URDF ingestion (host-only). The reference loads robots from URDF through sai2-model (e.g.
+ * examples/05-using_robot_controller/05-using_robot_controller.cpp:45-47 with panda_arm.urdf): this
+ * reads the same files into a sai2b_robot_model. Scope: one serial chain of exactly SAI2B_DOF revolute
+ * (or continuous) joints about their local z axis, any fixed joints (the bodies behind them are
+ * merged into the link they hang on, as RBDL does), rotated <inertial> frames. `urdf` is a file name
+ * (is_file != 0) or the XML text. `links` (may be NULL) receives, for every URDF link, the moving
+ * link it is rigidly attached to (-1: the world) and its fixed pose there. */
+#define SAI2B_URDF_MAX_LINKS 32
+typedef struct sai2b_urdf_links {
+	int n_links;
+	char name[SAI2B_URDF_MAX_LINKS][64];
+	int moving_link[SAI2B_URDF_MAX_LINKS];
+	double pos[SAI2B_URDF_MAX_LINKS][3];
+	double rot[SAI2B_URDF_MAX_LINKS][9]; /* row-major */
+} sai2b_urdf_links;
+int sai2b_model_from_urdf(const char* urdf, int is_file, sai2b_robot_model* model,
+						  sai2b_urdf_links* links);
+/* MotionForceTask takes a link NAME and a compliant frame in that link (MotionForceTask.h:96-101,
+ * e.g. "end-effector", a body on a fixed joint of link7): resolve them to the moving link index and
+ * the frame in it that sai2b_default_motion_force_task() takes. rot_in_link / frame_rot may be NULL. */
+int sai2b_urdf_resolve_frame(const sai2b_urdf_links* links, const char* link_name,
+							 const double pos_in_link[3], const double* rot_in_link, int* moving_link,
+							 double frame_pos[3], double frame_rot[9]);
+
 /* JointTask::JointTask + initialSetup defaults (JointTask.cpp:14-89, JointTask.h:31-45).
  * selection == NULL -> full joint task; else row-major task_dof x SAI2B_DOF, must be full row rank
  * (JointTask.cpp:34-39). */

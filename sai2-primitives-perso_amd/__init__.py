@@ -22,6 +22,8 @@ from .controller import (  # noqa: F401,E402
     MotionForceTask,
     RobotController,
     joint_task_config,
+    model_from_urdf,
+    resolve_link_frame,
     motion_force_task_config,
     panda_model,
     task_configs,

@@ -119,6 +119,21 @@ class TaskConfig(C.Structure):
     ]
 
 
+URDF_MAX_LINKS = 32
+
+
+class UrdfLinks(C.Structure):
+    """sai2b_urdf_links"""
+
+    _fields_ = [
+        ("n_links", _i),
+        ("name", (C.c_char * 64) * URDF_MAX_LINKS),
+        ("moving_link", _i * URDF_MAX_LINKS),
+        ("pos", (_d * 3) * URDF_MAX_LINKS),
+        ("rot", (_d * 9) * URDF_MAX_LINKS),
+    ]
+
+
 def struct_to_dict(s):
     """Flatten a ctypes struct into plain python values (for comparisons in tests)."""
     out = {}
@@ -151,6 +166,8 @@ LIB_PATH = os.environ.get("SAI2B_LIB") or os.path.join(PKG_DIR, "csrc", "libsai2
 EXPORTS = [
     "sai2b_panda_model",
     "sai2b_model_merge_fixed_body",
+    "sai2b_model_from_urdf",
+    "sai2b_urdf_resolve_frame",
     "sai2b_default_joint_task",
     "sai2b_default_motion_force_task",
     "sai2b_validate_tasks",
@@ -216,6 +233,8 @@ def load_library():
     vp = C.c_void_p
     lib.sai2b_panda_model.argtypes = [P(RobotModel)]
     lib.sai2b_model_merge_fixed_body.argtypes = [P(RobotModel), _i, dp, dp, _d, dp, dp]
+    lib.sai2b_model_from_urdf.argtypes = [C.c_char_p, _i, P(RobotModel), P(UrdfLinks)]
+    lib.sai2b_urdf_resolve_frame.argtypes = [P(UrdfLinks), C.c_char_p, dp, dp, P(_i), dp, dp]
     lib.sai2b_default_joint_task.argtypes = [P(TaskConfig), C.c_char_p, _i, dp]
     lib.sai2b_default_motion_force_task.argtypes = [P(TaskConfig), C.c_char_p, _i, dp, dp, _i, dp, _i, dp]
     lib.sai2b_validate_tasks.argtypes = [P(TaskConfig), _i, C.c_char_p, _i]

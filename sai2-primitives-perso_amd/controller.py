@@ -41,6 +41,24 @@ def panda_model():
     return m
 
 
+def model_from_urdf(urdf, is_file=True):
+    """sai2b_model_from_urdf(): (RobotModel, UrdfLinks) from a URDF file name or XML text"""
+    lib = _abi.load_library()
+    m, links = RobotModel(), _abi.UrdfLinks()
+    _check(lib, None, lib.sai2b_model_from_urdf(urdf.encode(), 1 if is_file else 0, C.byref(m), C.byref(links)))
+    return m, links
+
+
+def resolve_link_frame(links, link_name, pos_in_link=(0.0, 0.0, 0.0), rot_in_link=None):
+    """sai2b_urdf_resolve_frame(): link name + frame in that link -> (moving link index, frame_pos, frame_rot)"""
+    lib = _abi.load_library()
+    p = np.ascontiguousarray(pos_in_link, dtype=np.float64)
+    r = None if rot_in_link is None else np.ascontiguousarray(rot_in_link, dtype=np.float64)
+    link, fp, fr = C.c_int(), np.zeros(3), np.zeros(9)
+    _check(lib, None, lib.sai2b_urdf_resolve_frame(C.byref(links), link_name.encode(), _dp(p), _dp(r), C.byref(link), _dp(fp), _dp(fr)))
+    return link.value, fp, fr.reshape(3, 3)
+
+
 def joint_task_config(name=None, selection=None, internal_otg=False):
     """sai2b_default_joint_task(): JointTask ctor + defaults (JointTask.cpp:14-89).
     The library default is the reference's: internal OTG on (JointTask.h:38). This helper turns it
@@ -306,9 +324,12 @@ class BatchedRobotModel:
     model plus the batch size and the device; q/dq are set on it as on the reference's model
     (examples/05-using_robot_controller.cpp:143-145)."""
 
-    def __init__(self, batch, model=None, device=0):
+    def __init__(self, batch, model=None, device=0, urdf_file=None):
         self.batch = int(batch)
         self.device = int(device)
+        self.links = None
+        if urdf_file is not None:  # Sai2Model::Sai2Model(urdf_file) (examples/05-...cpp:96-97)
+            model, self.links = model_from_urdf(urdf_file)
         self.model = model if model is not None else panda_model()
         self._q = np.zeros((DOF, self.batch))
         self._dq = np.zeros((DOF, self.batch))
@@ -489,6 +510,10 @@ class MotionForceTask(_TaskBase):
                 np.zeros((0, 3)) if controlled_directions_translation is None else controlled_directions_translation,
                 np.zeros((0, 3)) if controlled_directions_rotation is None else controlled_directions_rotation,
             )
+        if isinstance(link, str):  # a link NAME as in the reference: needs a robot built from a URDF file
+            if robot.links is None:
+                raise ValueError("link names need a robot model built from a URDF file")
+            link, compliant_frame_pos, compliant_frame_rot = resolve_link_frame(robot.links, link, compliant_frame_pos, compliant_frame_rot)
         cfg = motion_force_task_config(task_name, link, compliant_frame_pos, compliant_frame_rot, partial,
                                        internal_otg=True)  # MotionForceTask.h:67
         cfg.parametrization_in_compliant_frame = int(is_force_motion_parametrization_in_compliant_frame)

@@ -171,6 +171,9 @@ static int full_pivot_rank(int rows, int cols, const double* A_in) {
 // ------------------------------------------------------------------------------------------------
 // configuration helpers (host only)
 // ------------------------------------------------------------------------------------------------
+// used by the host-only translation units of the library (sai2b_urdf.cpp)
+extern "C" int sai2b_set_global_error(int code, const char* msg) { return set_error(nullptr, code, msg ? msg : ""); }
+
 extern "C" int sai2b_model_merge_fixed_body(sai2b_robot_model* md, int link, const double xyz[3], const double rpy[3],
 											double mass, const double com[3], const double inertia[6]) {
 	if (!md || link < 0 || link >= N || !xyz || !rpy || !com || !inertia)
