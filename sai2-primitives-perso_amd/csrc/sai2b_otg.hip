@@ -20,6 +20,7 @@
 #include "sai2b_device.hpp"
 #include "sai2b_launch.h"
 #include "sai2b_otg_core.hpp"
+#include "sai2b_otg_group.hpp"
 
 namespace sai2b {
 namespace {
@@ -35,6 +36,13 @@ DI void store7(real* S, int row0, int n, int B, int b, const double (&v)[MD]) {
 		if (d < n) st(S, row0 + d, B, b, v[d]);
 }
 DI int ldflag(const real* S, int row, int B, int b) { return (int)ld(S, row, B, b); }
+// element j of a batch-uniform 7-vector (scalar registers) without dynamic indexing
+DI double sel7(const double (&v)[MD], int j) {
+	double r = v[0];
+	UNROLL for (int k = 1; k < MD; k++)
+		if (k == j) r = v[k];
+	return r;
+}
 
 // flags and the wrapper's target: enough to decide whether anything happens this tick
 DI void load_head(const real* S, int n, bool cart, int B, int b, Gen& g) {
@@ -85,19 +93,6 @@ DI void load_body(const real* S, int n, bool cart, int B, int b, Gen& g) {
 		UNROLL for (int i = 0; i < 9; i++) g.ref[i] = ld(S, OTG_CART + i, B, b);
 	}
 }
-DI void store_traj(real* S, int n, int B, int b, const Gen& g) {
-	st(S, OTG_DURATION, B, b, g.traj.duration);
-	UNROLL for (int d = 0; d < MD; d++)
-		if (d < n) {
-			const otg::Dof& f = g.traj.dof[d];
-			const otg::Prof& p = g.traj.prof[d];
-			const int r = OTG_TRAJ + d * OTG_TRAJ_STRIDE;
-			st(S, r, B, b, f.brake_t), st(S, r + 1, B, b, f.brake_a), st(S, r + 2, B, b, f.brake_p);
-			st(S, r + 3, B, b, f.brake_v), st(S, r + 4, B, b, f.p0), st(S, r + 5, B, b, f.v0);
-			st(S, r + 6, B, b, p.t0), st(S, r + 7, B, b, p.t1), st(S, r + 8, B, b, p.t2), st(S, r + 9, B, b, p.t6);
-			st(S, r + 10, B, b, p.a0), st(S, r + 11, B, b, p.a2), st(S, r + 12, B, b, p.a6);
-		}
-}
 DI void store_state(real* S, int n, bool cart, int B, int b, const Gen& g) {
 	store7(S, OTG_IN, n, B, b, g.in.cp);
 	store7(S, OTG_IN + MD, n, B, b, g.in.cv);
@@ -147,10 +142,6 @@ DI void store_desired_cart(real* D, int B, int b, const Gen& g) {
 		st(D, 21 + k, B, b, al[k]);
 	}
 	UNROLL for (int k = 0; k < 9; k++) st(D, 3 + k, B, b, R[k]);
-}
-
-DI void limits_of(const DevTask& t, double (&vmax)[MD], double (&amax)[MD]) {
-	UNROLL for (int d = 0; d < MD; d++) vmax[d] = t.otg_vmax[d], amax[d] = t.otg_amax[d];
 }
 
 // goals of one robot as the wrappers' setGoal... calls take them
@@ -267,35 +258,96 @@ DI void sample_lane(const DevTask& t, bool cart, int n, int B, int b, Gen& g) {
 		store_desired_joints(t.otg_desired, n, B, b, g);
 }
 
-// PLAN: the whole computeTorques-time sequence setGoal...(goal); update(); (JointTask.cpp:314-315,
-// MotionForceTask.cpp:395-399) with one call site of the planner for both wrapper kinds
-DI void plan_lane(const DevTask& t, bool cart, int n, int B, int b, Gen& g, const Goals& G) {
+// PLAN, one DoF per lane (sai2b_otg_group.hpp): the whole computeTorques-time sequence
+// setGoal...(goal); update(); (JointTask.cpp:314-315, MotionForceTask.cpp:395-399) for robot b by the
+// caller's group of 8 lanes
+DI void plan_group(const DevTask& t, bool cart, int n, int B, int b) {
+	using namespace otgg;
 	real* S = t.otg_state;
-	load_body(S, n, cart, B, b, g);
-	double vmax[MD], amax[MD];
-	limits_of(t, vmax, amax);
-	if (cart) {
-		otg::cart_set_goal_position(g, G.cp, G.cv);
-		otg::cart_set_goal_orientation(g, G.cR, G.cw);
-	} else {
-		otg::joints_set_goal(g, n, G.jp, G.jv);
+	const int j = lane_j();
+	const bool active = j < n;
+	auto row = [&](int r0) { return active ? ld(S, r0 + j, B, b) : 0.0; };
+	LaneGen g;
+	g.in_cp = row(OTG_IN), g.in_cv = row(OTG_IN + MD), g.in_ca = row(OTG_IN + 2 * MD), g.in_tp = row(OTG_IN + 3 * MD),
+	g.in_tv = row(OTG_IN + 4 * MD);
+	g.ci_cp = row(OTG_CI), g.ci_cv = row(OTG_CI + MD), g.ci_ca = row(OTG_CI + 2 * MD), g.ci_tp = row(OTG_CI + 3 * MD),
+	g.ci_tv = row(OTG_CI + 4 * MD);
+	g.np = row(OTG_OUT), g.nv = row(OTG_OUT + MD), g.na = row(OTG_OUT + 2 * MD);
+	{
+		const int r = OTG_TRAJ + (active ? j : 0) * OTG_TRAJ_STRIDE;
+		g.f.brake_t = ld(S, r, B, b), g.f.brake_a = ld(S, r + 1, B, b), g.f.brake_p = ld(S, r + 2, B, b);
+		g.f.brake_v = ld(S, r + 3, B, b), g.f.p0 = ld(S, r + 4, B, b), g.f.v0 = ld(S, r + 5, B, b);
+		g.f.pf = g.f.vf = 0;
+		g.p.t0 = ld(S, r + 6, B, b), g.p.t1 = ld(S, r + 7, B, b), g.p.t2 = ld(S, r + 8, B, b), g.p.t6 = ld(S, r + 9, B, b);
+		g.p.a0 = ld(S, r + 10, B, b), g.p.a2 = ld(S, r + 11, B, b), g.p.a6 = ld(S, r + 12, B, b);
+		g.p.dur = ((g.p.t0 + g.p.t1) + g.p.t2) + g.p.t6;
+		g.p.dir = 0;
 	}
+	g.time = ld(S, OTG_TIME, B, b);
+	g.duration = ld(S, OTG_DURATION, B, b);
+	g.goal_reached = ldflag(S, OTG_GOAL_REACHED, B, b);
+	g.result = ldflag(S, OTG_RESULT, B, b);
+	g.target_set = ldflag(S, OTG_TARGET_SET, B, b);
+	g.ci_init = ldflag(S, OTG_CI_INIT, B, b);
+	g.ci_epoch = ld(S, OTG_CI_EPOCH, B, b);
 	g.replanned = 0;
-	if (!g.goal_reached) {
-		otg::Prev pv;
-		otg::save_prev(g, pv);
-		g.result = otg::ruckig_update(g, n, t.dt, vmax, amax, t.otg_epoch);
-		if (cart)
-			otg::cart_finish(g, pv);
-		else
-			otg::joints_finish(g, n, pv);
+	const double vmax = active ? sel7(t.otg_vmax, j) : 0.0, amax = active ? sel7(t.otg_amax, j) : 0.0;
+	if (cart) {
+		UNROLL for (int i = 0; i < 9; i++) g.ref[i] = ld(S, OTG_CART + i, B, b), g.goal_R[i] = ld(S, OTG_CART + 9 + i, B, b);
+		UNROLL for (int i = 0; i < 3; i++) g.goal_w[i] = ld(S, OTG_CART + 18 + i, B, b);
+		real gR[9], gw[3];
+		UNROLL for (int k = 0; k < 9; k++) gR[k] = ld(t.goals, 3 + k, B, b);
+		UNROLL for (int k = 0; k < 3; k++) gw[k] = ld(t.goals, 15 + k, B, b);
+		const double gp = j < 3 ? ld(t.goals, j, B, b) : 0.0, gv = j < 3 ? ld(t.goals, 12 + j, B, b) : 0.0;
+		cart_set_goal_position(g, gp, gv);
+		cart_set_goal_orientation(g, gR, gw);
+	} else {
+		const double gp = active ? ld(t.goals, j, B, b) : 0.0, gv = active ? ld(t.goals, n + j, B, b) : 0.0;
+		joints_set_goal(g, active, n, gp, gv);
 	}
-	store_state(S, n, cart, B, b, g);
-	if (g.replanned) store_traj(S, n, B, b, g);
-	if (cart)
-		store_desired_cart(t.otg_desired, B, b, g);
-	else
-		store_desired_joints(t.otg_desired, n, B, b, g);
+	update(g, cart, active, n, t.dt, vmax, amax, t.otg_epoch);
+
+	auto put = [&](int r0, double v) {
+		if (active) st(S, r0 + j, B, b, v);
+	};
+	put(OTG_IN, g.in_cp), put(OTG_IN + MD, g.in_cv), put(OTG_IN + 2 * MD, g.in_ca), put(OTG_IN + 3 * MD, g.in_tp), put(OTG_IN + 4 * MD, g.in_tv);
+	put(OTG_CI, g.ci_cp), put(OTG_CI + MD, g.ci_cv), put(OTG_CI + 2 * MD, g.ci_ca), put(OTG_CI + 3 * MD, g.ci_tp), put(OTG_CI + 4 * MD, g.ci_tv);
+	put(OTG_OUT, g.np), put(OTG_OUT + MD, g.nv), put(OTG_OUT + 2 * MD, g.na);
+	if (g.replanned && active) {
+		const int r = OTG_TRAJ + j * OTG_TRAJ_STRIDE;
+		st(S, r, B, b, g.f.brake_t), st(S, r + 1, B, b, g.f.brake_a), st(S, r + 2, B, b, g.f.brake_p);
+		st(S, r + 3, B, b, g.f.brake_v), st(S, r + 4, B, b, g.f.p0), st(S, r + 5, B, b, g.f.v0);
+		st(S, r + 6, B, b, g.p.t0), st(S, r + 7, B, b, g.p.t1), st(S, r + 8, B, b, g.p.t2), st(S, r + 9, B, b, g.p.t6);
+		st(S, r + 10, B, b, g.p.a0), st(S, r + 11, B, b, g.p.a2), st(S, r + 12, B, b, g.p.a6);
+	}
+	real R[9], w[3], al[3];
+	if (cart) {	 // getNextOrientation / getNextAngular* (OTG_6dof_cartesian.cpp:226-237, .h:222-227)
+		real local[9];
+		otg::vec_to_rot(gget(g.np, 3), gget(g.np, 4), gget(g.np, 5), local);
+		otg::mat3_mul(g.ref, local, R);
+		otg::mat3_vec(g.ref, gget(g.nv, 3), gget(g.nv, 4), gget(g.nv, 5), w);
+		otg::mat3_vec(g.ref, gget(g.na, 3), gget(g.na, 4), gget(g.na, 5), al);
+	}
+	if (j == 0) {
+		st(S, OTG_TIME, B, b, g.time);
+		if (g.replanned) st(S, OTG_DURATION, B, b, g.duration);
+		st(S, OTG_GOAL_REACHED, B, b, (double)g.goal_reached);
+		st(S, OTG_RESULT, B, b, (double)g.result);
+		st(S, OTG_TARGET_SET, B, b, (double)g.target_set);
+		st(S, OTG_CI_INIT, B, b, (double)g.ci_init);
+		st(S, OTG_CI_EPOCH, B, b, g.ci_epoch);
+		if (cart) {
+			UNROLL for (int i = 0; i < 9; i++) st(S, OTG_CART + i, B, b, g.ref[i]), st(S, OTG_CART + 9 + i, B, b, g.goal_R[i]);
+			UNROLL for (int i = 0; i < 3; i++) st(S, OTG_CART + 18 + i, B, b, g.goal_w[i]);
+			UNROLL for (int k = 0; k < 9; k++) st(t.otg_desired, 3 + k, B, b, R[k]);
+			UNROLL for (int k = 0; k < 3; k++) st(t.otg_desired, 15 + k, B, b, w[k]), st(t.otg_desired, 21 + k, B, b, al[k]);
+		}
+	}
+	if (cart) {
+		if (j < 3) st(t.otg_desired, j, B, b, g.np), st(t.otg_desired, 12 + j, B, b, g.nv), st(t.otg_desired, 18 + j, B, b, g.na);
+	} else if (active) {
+		st(t.otg_desired, j, B, b, g.np), st(t.otg_desired, n + j, B, b, g.nv), st(t.otg_desired, 2 * n + j, B, b, g.na);
+	}
 }
 
 }  // namespace
@@ -339,27 +391,27 @@ __global__ __launch_bounds__(64) void otg_kernel(const DevParams* __restrict__ P
 	}
 }
 
-// The robots otg_kernel left over (goal changed / input differs), compacted: lane i of the grid takes
-// entry i of the task's list. Classification is repeated from the untouched state, which also
-// re-loads what the full update needs.
+// The robots otg_kernel left over (goal changed / input differs), compacted: group i (8 lanes, one DoF
+// per lane) of the grid takes entry i of the task's list and does the robot's full update.
 __global__ __launch_bounds__(64) void otg_plan_kernel(const DevParams* __restrict__ Pp, int* __restrict__ counts,
 													  const int* __restrict__ list, int parity) {
 	const DevParams& P = *Pp;
 	const int B = P.B;
-	const int i = blockIdx.x * 64 + threadIdx.x;
-	if (i < SAI2B_MAX_TASKS) ((gint*)counts)[(1 - parity) * SAI2B_MAX_TASKS + i] = 0;  // next tick's counters
+	if (blockIdx.x == 0 && threadIdx.x < SAI2B_MAX_TASKS) ((gint*)counts)[(1 - parity) * SAI2B_MAX_TASKS + threadIdx.x] = 0;  // next tick's counters
+	constexpr int GROUPS = 64 / otgg::G;
 #pragma unroll 1
 	for (int t = 0; t < P.n_tasks; t++) {
 		const DevTask& tk = P.task[t];
 		if (!tk.otg_on) continue;
 		const int cnt = ((const gint*)counts)[parity * SAI2B_MAX_TASKS + t];
-		if (blockIdx.x * 64 >= cnt) continue;  // uniform over the wavefront
-		if (i >= cnt) continue;
-		const int b = ((const gint*)list)[(size_t)t * B + i];
-		const bool cart = tk.type == SAI2B_MOTION_FORCE_TASK;
-		Gen g;
-		Goals G;
-		if (classify(tk, cart, tk.otg_n, B, b, g, G) == PLAN) plan_lane(tk, cart, tk.otg_n, B, b, g, G);
+		// grid-stride over the list: the grid is sized for the machine, not for the worst-case list
+#pragma unroll 1
+		for (int e0 = blockIdx.x * GROUPS; e0 < cnt; e0 += gridDim.x * GROUPS) {  // uniform over the wavefront
+			const int e = e0 + threadIdx.x / otgg::G;
+			if (e >= cnt) continue;	 // uniform over the group
+			const int b = ((const gint*)list)[(size_t)t * B + e];
+			plan_group(tk, tk.type == SAI2B_MOTION_FORCE_TASK, tk.otg_n, B, b);
+		}
 	}
 }
 
@@ -442,7 +494,8 @@ extern "C" int sai2b_launch_otg(const sai2b::DevParams* d_params, int B, int* co
 								hipStream_t stream) {
 	const dim3 grid((B + 63) / 64), block(64);
 	hipLaunchKernelGGL(sai2b::otg_kernel, grid, block, 0, stream, d_params, counts, list, parity);
-	hipLaunchKernelGGL(sai2b::otg_plan_kernel, grid, block, 0, stream, d_params, counts, (const int*)list, parity);
+	const int plan_blocks = (B + 7) / 8 < 2048 ? (B + 7) / 8 : 2048;
+	hipLaunchKernelGGL(sai2b::otg_plan_kernel, dim3(plan_blocks), block, 0, stream, d_params, counts, (const int*)list, parity);
 	return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

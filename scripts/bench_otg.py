@@ -16,6 +16,7 @@ import oracle_lib as ol
 import sai2_primitives_perso_amd as pkg
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+ONLY_MOVING = len(sys.argv) > 2 and sys.argv[2] == "moving"  # profiling runs: just the all-moving phase
 inp = pkg.workloads.make_inputs(3, B=B)
 
 
@@ -38,17 +39,19 @@ def make(otg):
     return c
 
 
-c = make(False)
-ol.load_inputs(c, inp)
-timed(c, 20)
-off = timed(c, 200)
-print(f"OTG off            : {off * 1e6:7.1f} us/step  {B / off / 1e9:.2f} G ticks/s")
-c.close()
+if not ONLY_MOVING:
+    c = make(False)
+    ol.load_inputs(c, inp)
+    timed(c, 20)
+    off = timed(c, 200)
+    print(f"OTG off            : {off * 1e6:7.1f} us/step  {B / off / 1e9:.2f} G ticks/s")
+    c.close()
 
 c = make(True)
 timed(c, 20)  # goals = current pose: every generator finishes at once
-idle = timed(c, 200)
-print(f"OTG on, idle       : {idle * 1e6:7.1f} us/step  {B / idle / 1e9:.2f} G ticks/s   reached={c.get_otg_status(1)[0].mean():.2f}")
+if not ONLY_MOVING:
+    idle = timed(c, 200)
+    print(f"OTG on, idle       : {idle * 1e6:7.1f} us/step  {B / idle / 1e9:.2f} G ticks/s   reached={c.get_otg_status(1)[0].mean():.2f}")
 
 # far goals: ~1 s trajectories, every robot moving during the timed region
 far_q = inp["q"] + 0.8 * np.sign(np.random.default_rng(0).normal(size=inp["q"].shape))
@@ -70,6 +73,10 @@ def regoal(k):
     c.set_jt_goals(1, G[k % 4], None, None)
     c.set_mft_goals(0, P[k % 4], None, None, None, None, None)
 
+
+if ONLY_MOVING:
+    c.close()
+    sys.exit(0)
 
 # 1 % of the robots get a new goal each tick (a different 1 % every time)
 rng = np.random.default_rng(1)
