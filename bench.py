@@ -182,7 +182,9 @@ def main():
                 "note": "achieved = algorithmic bytes/tick (SURVEY.md §8(d): 360/528/576 B for C2/C3/C4) x robots per launch / HIP-event duration of the "
                         "dominant kernel; the path is FP64-VALU/latency bound, so the FP64 fraction (11.4 kflop/tick "
                         "formula-level figure) is reported beside the HBM fraction. traffic = 2*FETCH_SIZE + WRITE_SIZE "
-                        "of the committed rocprofv3 --pmc passes of this command (profiles/), per launch",
+                        "of the committed rocprofv3 --pmc passes of this command (profiles/), per launch. Measured FP64 FMA "
+                        "issue ceilings (profiles/r01_fp64_fma_microbench.txt): 60 TF chip peak, 30 TF with one wavefront "
+                        "per SIMD, which is what 65 536 robots at one lane per robot give",
             },
         }
         if not args.no_cpu_baseline and world == 1:
