@@ -220,7 +220,6 @@ DI void load_traj(const real* S, int n, bool cart, int B, int b, Gen& g) {
 DI void sample_lane(const DevTask& t, bool cart, int n, int B, int b, Gen& g) {
 	real* S = t.otg_state;
 	load_traj(S, n, cart, B, b, g);
-	const int target_set0 = g.target_set;
 	g.result = otg::ruckig_sample(g, n, t.dt, otg::WORKING);
 	otg::Prev none;	 // the error branch cannot be taken without a calculation
 	if (cart)
@@ -251,7 +250,6 @@ DI void sample_lane(const DevTask& t, bool cart, int n, int B, int b, Gen& g) {
 			}
 		}
 	}
-	(void)target_set0;
 	if (cart)
 		store_desired_cart(t.otg_desired, B, b, g);
 	else
