@@ -41,7 +41,7 @@ def pmc_traffic_bytes():
         return None
     data = json.load(open(files[-1]))
     for name, c in data.items():
-        if "tick_fast_kernel<2>" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        if "tick_fast_kernel<2" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             return (2 * c["FETCH_SIZE"]["avg_per_dispatch"] + c["WRITE_SIZE"]["avg_per_dispatch"]) * 1024
     return None
 
