@@ -35,6 +35,10 @@ struct sai2b_ctx {
 	int* otg_counts = nullptr;	// [2][MAX_TASKS] work-list counters of the trajectory planner (sai2b_otg.hip)
 	int* otg_list = nullptr;	// [MAX_TASKS][B] robots that need the planner this tick
 	int otg_parity = 0;
+	// bit t set: task t's goals may have changed since the last OTG update (setters, reinitialize, config
+	// updates); goals_exposed: the caller holds the device pointer of some goals buffer, so always assume it
+	unsigned goals_dirty = ~0u;
+	bool goals_exposed = false;
 	sai2b_robot_model model;
 	sai2b_task_config cfg[SAI2B_MAX_TASKS];
 	DevParams h_params;
@@ -640,6 +644,7 @@ extern "C" int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_ta
 	d.otg_desired = keep.otg_desired, d.otg_state = keep.otg_state, d.otg_epoch = keep.otg_epoch;
 	d.law_goals = d.otg_on ? d.otg_desired : d.goals;
 	ctx->params_dirty = true;
+	ctx->goals_dirty |= 1u << task;
 	// enableInternalOtgAccelerationLimited (JointTask.cpp:360-381, MotionForceTask.cpp:511-523) is
 	// applied when the OTG fields change: new limits make every moving robot re-plan
 	// (InputParameter::operator!=, input_parameter.hpp:362-394); a generator that was off is
@@ -695,6 +700,7 @@ extern "C" int sai2b_set_mft_goals(sai2b_ctx* ctx, int task, const double* pos, 
 	if (rc) return rc;
 	double* G = ctx->h_params.task[task].goals;
 	const size_t B = ctx->B;
+	ctx->goals_dirty |= 1u << task;
 	if ((rc = copy_rows(ctx, G, pos, 3, on_device))) return rc;
 	if ((rc = copy_rows(ctx, G + 3 * B, rot, 9, on_device))) return rc;
 	if ((rc = copy_rows(ctx, G + 12 * B, lin_vel, 3, on_device))) return rc;
@@ -728,6 +734,7 @@ extern "C" int sai2b_set_jt_goals(sai2b_ctx* ctx, int task, const double* q_goal
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	double* G = ctx->h_params.task[task].goals;
 	const size_t B = ctx->B, k0 = ctx->cfg[task].task_dof;
+	ctx->goals_dirty |= 1u << task;
 	int rc;
 	if ((rc = copy_rows(ctx, G, q_goal, k0, on_device))) return rc;
 	if ((rc = copy_rows(ctx, G + k0 * B, dq_goal, k0, on_device))) return rc;
@@ -742,6 +749,7 @@ extern "C" int sai2b_reinitialize(sai2b_ctx* ctx) {
 	if (sai2b_launch_reinit(ctx->d_params, ctx->B, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "reinit launch failed");
 	if (sai2b_launch_otg_reinit(ctx->d_params, ctx->B, -1, 0, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG reinit launch failed");
+	ctx->goals_dirty = ~0u;
 	ctx->launches += 2;
 	ctx->models_fresh = false;
 	return SAI2B_OK;
@@ -770,7 +778,9 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 	if (rc) return rc;
 	const int fast = fast_kind(ctx);
 	if (do_torque && any_otg(ctx)) {  // the generators advance once per torque computation, before the law
-		if (sai2b_launch_otg(ctx->d_params, ctx->B, ctx->otg_counts, ctx->otg_list, ctx->otg_parity, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG launch failed");
+		const int clean_mask = ctx->goals_exposed ? 0 : (int)(~ctx->goals_dirty & ((1u << SAI2B_MAX_TASKS) - 1u));
+		ctx->goals_dirty = 0;
+		if (sai2b_launch_otg(ctx->d_params, ctx->B, ctx->otg_counts, ctx->otg_list, ctx->otg_parity, clean_mask, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG launch failed");
 		ctx->otg_parity ^= 1;
 		ctx->launches += 2;
 	}
@@ -834,7 +844,9 @@ extern "C" void* sai2b_device_buffer(sai2b_ctx* ctx, int which, int task) {
 		case SAI2B_BUF_Q: return ctx->q;
 		case SAI2B_BUF_DQ: return ctx->dq;
 		case SAI2B_BUF_TAU: return ctx->tau;
-		case SAI2B_BUF_GOALS: return task_ok ? ctx->h_params.task[task].goals : nullptr;
+		case SAI2B_BUF_GOALS:
+			if (task_ok) ctx->goals_exposed = true;	 // the caller may now write goals behind the library's back
+			return task_ok ? ctx->h_params.task[task].goals : nullptr;
 		case SAI2B_BUF_SENSED: return task_ok ? ctx->h_params.task[task].sensed : nullptr;
 		case SAI2B_BUF_STATE: return task_ok ? ctx->h_params.task[task].state : nullptr;
 	}

@@ -169,8 +169,12 @@ DI void load_goals(const DevTask& t, bool cart, int n, int B, int b, Goals& G) {
 //   PLAN    the goal changed (setGoal... will touch the input) or the input differs from the stored
 //           one (ruckig.hpp:194): the full update with the planner, done by otg_plan_kernel.
 enum { IDLE = 0, SAMPLE = 1, PLAN = 2 };
-DI int classify(const DevTask& t, bool cart, int n, int B, int b, Gen& g, Goals& G) {
+DI int classify(const DevTask& t, bool cart, int n, int B, int b, Gen& g, Goals& G, bool goals_clean) {
 	const real* S = t.otg_state;
+	// The host has not touched this task's goals (nor its OTG configuration) since the previous
+	// update: for a robot whose goal is reached setGoal...() is the same no-op as last time, so its
+	// flag alone decides (1 row instead of ~35)
+	if (goals_clean && ldflag(S, OTG_GOAL_REACHED, B, b) != 0) return IDLE;
 	load_head(S, n, cart, B, b, g);
 	load_goals(t, cart, n, B, b, G);
 	bool unchanged;
@@ -359,7 +363,7 @@ DI void plan_group(const DevTask& t, bool cart, int n, int B, int b) {
 // that need the planner are appended to the task's work list (one atomic per wavefront, lanes of a
 // wavefront stay adjacent and ordered, so the plan kernel's accesses coalesce in runs).
 __global__ __launch_bounds__(64) void otg_kernel(const DevParams* __restrict__ Pp, int* __restrict__ counts,
-												 int* __restrict__ list, int parity) {
+												 int* __restrict__ list, int parity, int clean_mask) {
 	const DevParams& P = *Pp;
 	const int B = P.B;
 	const int b = blockIdx.x * 64 + threadIdx.x;
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(64) void otg_kernel(const DevParams* __restrict__ P
 		if (live) {
 			Gen g;
 			Goals G;
-			cls = classify(tk, cart, tk.otg_n, B, b, g, G);
+			cls = classify(tk, cart, tk.otg_n, B, b, g, G, ((clean_mask >> t) & 1) != 0);
 			if (cls == SAMPLE) sample_lane(tk, cart, tk.otg_n, B, b, g);
 		}
 		const unsigned long long mask = __ballot(cls == PLAN);
@@ -488,10 +492,11 @@ __global__ __launch_bounds__(64) void otg_reinit_kernel(const DevParams* __restr
 
 // counts: [2][SAI2B_MAX_TASKS] ints, zero before the first call; list: [SAI2B_MAX_TASKS][B] ints;
 // parity alternates 0/1 between consecutive calls
-extern "C" int sai2b_launch_otg(const sai2b::DevParams* d_params, int B, int* counts, int* list, int parity,
+// clean_mask bit t: the host has not written task t's goals / OTG settings since the previous call
+extern "C" int sai2b_launch_otg(const sai2b::DevParams* d_params, int B, int* counts, int* list, int parity, int clean_mask,
 								hipStream_t stream) {
 	const dim3 grid((B + 63) / 64), block(64);
-	hipLaunchKernelGGL(sai2b::otg_kernel, grid, block, 0, stream, d_params, counts, list, parity);
+	hipLaunchKernelGGL(sai2b::otg_kernel, grid, block, 0, stream, d_params, counts, list, parity, clean_mask);
 	const int plan_blocks = (B + 7) / 8 < 2048 ? (B + 7) / 8 : 2048;
 	hipLaunchKernelGGL(sai2b::otg_plan_kernel, dim3(plan_blocks), block, 0, stream, d_params, counts, (const int*)list, parity);
 	return hipGetLastError() == hipSuccess ? 0 : 1;

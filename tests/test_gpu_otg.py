@@ -249,3 +249,51 @@ def test_gpu_facade_otg_on_by_default():
     jt.disableInternalOtg()
     ctl.tick()
     assert np.array_equal(jt.getDesiredPosition(), inp["jt1"]["q"])
+
+
+def test_gpu_otg_idle_shortcut_still_sees_new_goals():
+    """an idle generator is skipped from its flag alone while the host knows the goals are untouched;
+    a setter call (host array or device tensor) must end that, and so must handing out the goals'
+    device pointer (the caller may then write goals behind the library's back)"""
+    import torch
+
+    B = 128
+    inp = pkg.workloads.make_inputs(3, B=B, seed=6)
+    o, g = _c3_pair(B)
+    for c in (o, g):
+        c.set_state(inp["q"], inp["dq"])
+        c.reinitialize()
+    for _ in range(5):  # goals = current pose: everything idles after the first tick
+        to, tg = o.tick(), g.tick()
+    assert g.get_otg_status(1)[0].all() and _err(tg, to).max() < TOL
+    goal = inp["q"] + 0.05
+    for c in (o, g):
+        c.set_jt_goals(1, goal, None, None)
+    for _ in range(30):
+        to, tg = o.tick(), g.tick()
+    assert not g.get_otg_status(1)[0].any() and _err(tg, to).max() < TOL
+    assert np.abs(o.get_jt_desired(1)[0] - g.get_jt_desired(1)[0]).max() < 1e-12
+    for _ in range(600):  # finish and idle again
+        to, tg = o.tick(), g.tick()
+    assert g.get_otg_status(1)[0].all()
+    # goal from a device tensor
+    goal2 = goal - 0.03
+    g.set_jt_goals(1, torch.as_tensor(goal2, device="cuda"), None, None)
+    o.set_jt_goals(1, goal2, None, None)
+    for _ in range(700):
+        to, tg = o.tick(), g.tick()
+    assert g.get_otg_status(1)[0].all() and _err(tg, to).max() < TOL
+    # the device pointer of the goals is handed out: the caller overwrites the goals without any setter
+    ptr = g.device_buffer(pkg._abi.BUF_GOALS, 1)
+    goal3 = goal2 + 0.02
+    class _Raw:  # zero-copy torch view of the library's goals buffer (q, dq, ddq goals: [21][B])
+        __cuda_array_interface__ = {"data": (int(ptr), False), "shape": (21, B), "typestr": "<f8", "version": 2}
+
+    view = torch.as_tensor(_Raw(), device="cuda")
+    view[:7].copy_(torch.as_tensor(goal3, device="cuda"))
+    torch.cuda.synchronize()
+    o.set_jt_goals(1, goal3, None, None)
+    for _ in range(25):
+        to, tg = o.tick(), g.tick()
+    assert not g.get_otg_status(1)[0].any() and _err(tg, to).max() < TOL
+    assert np.abs(o.get_jt_desired(1)[0] - g.get_jt_desired(1)[0]).max() < 1e-12
