@@ -297,3 +297,37 @@ def test_gpu_otg_idle_shortcut_still_sees_new_goals():
         to, tg = o.tick(), g.tick()
     assert not g.get_otg_status(1)[0].any() and _err(tg, to).max() < TOL
     assert np.abs(o.get_jt_desired(1)[0] - g.get_jt_desired(1)[0]).max() < 1e-12
+
+
+def test_gpu_otg_reinitialize_mid_motion_ragged_batch():
+    """reinitializeTasks() while the generators are moving (OTG objects re-initialised at the current
+    pose, goals reset), a batch that fills neither a wavefront nor the planner's 8-lane groups, and two
+    controllers alive on the device at once"""
+    B = 70
+    inp = pkg.workloads.make_inputs(3, B=B, seed=13)
+    o, g = _c3_pair(B)
+    o2, g2 = _c3_pair(B)  # a second, independent pair: contexts must not share any state
+    rng = np.random.default_rng(2)
+    for c in (o, g, o2, g2):
+        c.set_state(inp["q"], inp["dq"])
+        c.reinitialize()
+    goal = inp["q"] + rng.normal(0, 0.15, (N, B))
+    for c in (o, g):
+        c.set_jt_goals(1, goal, None, None)
+        c.set_mft_goals(0, inp["mft0"]["pos"], inp["mft0"]["rot"], None, None, None, None)
+    for c in (o2, g2):
+        c.set_jt_goals(1, goal[::-1].copy(), None, None)
+    for tick in range(120):
+        if tick == 60:
+            q2 = inp["q"] + 0.01
+            for c in (o, g):
+                c.set_state(q2, inp["dq"])
+                c.reinitialize()
+                c.set_jt_goals(1, goal, None, None)
+        to, tg = o.tick(), g.tick()
+        t2o, t2g = o2.tick(), g2.tick()
+        assert _err(tg, to).max() < TOL and _err(t2g, t2o).max() < TOL, tick
+        for a, b_ in zip(o.get_jt_desired(1) + o.get_mft_desired(0), g.get_jt_desired(1) + g.get_mft_desired(0)):
+            assert np.abs(a - b_).max() < 1e-12, tick
+    for a, b_ in zip(o.get_otg_status(1) + o2.get_otg_status(1), g.get_otg_status(1) + g2.get_otg_status(1)):
+        assert np.array_equal(a, b_)
