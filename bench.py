@@ -50,6 +50,7 @@ def cpu_baseline(inp, seconds=8.0):
     """the CPU oracle (our FP64 restatement of the reference, -O2) timed on this host's cores on a
     bounded sample of the same workload"""
     import oracle_lib as ol
+    import sai2_primitives_perso_amd as pkg
 
     sample = 8192
     sub = {"B": sample, "tasks": inp["tasks"], "q": np.ascontiguousarray(inp["q"][:, :sample]),
@@ -62,7 +63,7 @@ def cpu_baseline(inp, seconds=8.0):
     res = {}
     for label, threads in (("single", 1), ("all", cores)):
         o = ol.Oracle(ol.panda_model(), ol.task_configs(sub["tasks"]), sample, threads=threads)
-        ol.load_inputs(o, sub)
+        pkg.workloads.load_inputs(o, sub)
         o.tick(want_output=False)
         n, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < seconds / 2:
@@ -108,9 +109,8 @@ def main():
     B = args.batch or (65536 if args.config in (3, 5) else pkg.workloads.CONFIG_BATCH[args.config])
     inp = pkg.workloads.make_inputs(args.config if args.config != 5 else 3, B=B, rank=rank)
     ctrl = pkg.Controller(pkg.panda_model(), pkg.task_configs(inp["tasks"]), B, device=local_rank)
-    import oracle_lib as ol  # only for load_inputs (a plain setter loop) and the cpu_baseline leg
 
-    ol.load_inputs(ctrl, inp)  # H2D once: inputs are resident before the timed region
+    pkg.workloads.load_inputs(ctrl, inp)  # H2D once: inputs are resident before the timed region
     ctrl.synchronize()
     stream = torch.cuda.ExternalStream(ctrl.stream(), device=torch.device("cuda", local_rank))
 

@@ -168,3 +168,15 @@ def make_inputs(config, B=None, seed=None, rank=0):
                 "ddq": np.zeros((k0, B)),
             }
     return out
+
+
+def load_inputs(ctrl, inp):
+    """feed a make_inputs() dict to a controller object (state, then every task's goals)"""
+    ctrl.set_state(inp["q"], inp["dq"])
+    for t, (kind, _) in enumerate(inp["tasks"]):
+        if kind == "mft":
+            g = inp[f"mft{t}"]
+            ctrl.set_mft_goals(t, g["pos"], g["rot"], g["v"], g["w"], g["a"], g["alpha"])
+        else:
+            g = inp[f"jt{t}"]
+            ctrl.set_jt_goals(t, g["q"], g["dq"], g["ddq"])

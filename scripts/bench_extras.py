@@ -10,14 +10,13 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np
 import torch  # noqa: F401
 
-import oracle_lib as ol
 import sai2_primitives_perso_amd as pkg
 
 print("batch sweep, C3 hierarchy, inputs resident in HBM")
 for B in (4096, 16384, 65536, 131072, 262144, 524288):
     inp = pkg.workloads.make_inputs(3, B=B)
     c = pkg.Controller(pkg.panda_model(), pkg.task_configs(inp["tasks"]), B)
-    ol.load_inputs(c, inp)
+    pkg.workloads.load_inputs(c, inp)
     for _ in range(10):
         c.tick(want_output=False)
     c.synchronize()
@@ -32,11 +31,11 @@ for B in (4096, 16384, 65536, 131072, 262144, 524288):
         # PCIe-inclusive: state + all goals H2D, tick, torques D2H, every step (pageable numpy arrays)
         tau = np.empty((7, B))
         for _ in range(3):
-            ol.load_inputs(c, inp)
+            pkg.workloads.load_inputs(c, inp)
             c.tick(out=tau)
         t0 = time.perf_counter()
         for _ in range(10):
-            ol.load_inputs(c, inp)
+            pkg.workloads.load_inputs(c, inp)
             c.tick(out=tau)
         dt = (time.perf_counter() - t0) / 10
         nbytes = (14 + 24 + 21 + 7) * 8 * B

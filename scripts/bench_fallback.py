@@ -13,7 +13,6 @@ import numpy as np
 import torch  # noqa: F401
 
 import make_golden
-import oracle_lib as ol
 import sai2_primitives_perso_amd as pkg
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
@@ -23,7 +22,7 @@ for label, config, singular in (("[MFT]      regular", 2, False), ("[MFT]      s
     if singular:
         inp = make_golden.make_singular(inp)
     c = pkg.Controller(pkg.panda_model(), pkg.task_configs(inp["tasks"]), B)
-    ol.load_inputs(c, inp)
+    pkg.workloads.load_inputs(c, inp)
     for _ in range(5):
         c.tick(want_output=False)
     c.synchronize()

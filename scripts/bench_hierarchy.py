@@ -11,7 +11,6 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np
 import torch  # noqa: F401
 
-import oracle_lib as ol
 import sai2_primitives_perso_amd as pkg
 
 B = 65536
@@ -21,7 +20,7 @@ for label, frac in (("regular poses", 0.0), ("1 in 1000 near-singular", 0.001), 
     q = pkg.workloads.sample_poses(rng, B, reject_ratio=0.1 if frac == 0 else None, singular_fraction=frac)
     inp["q"] = np.ascontiguousarray(q.T)
     c = pkg.Controller(pkg.panda_model(), pkg.task_configs(inp["tasks"]), B)
-    ol.load_inputs(c, inp)
+    pkg.workloads.load_inputs(c, inp)
     for _ in range(5):
         c.tick(want_output=False)
     c.synchronize()

@@ -10,7 +10,6 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np
 import torch  # noqa: F401
 
-import oracle_lib as ol
 import sai2_primitives_perso_amd as pkg
 
 B = 65536
@@ -19,7 +18,7 @@ for K in (1, 2, 4, 8):
     for k in range(K):
         inp = pkg.workloads.make_inputs(3, B=B // K, rank=k)
         c = pkg.Controller(pkg.panda_model(), pkg.task_configs(inp["tasks"]), B // K)
-        ol.load_inputs(c, inp)
+        pkg.workloads.load_inputs(c, inp)
         ctrls.append(c)
     for _ in range(20):
         for c in ctrls:

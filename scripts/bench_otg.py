@@ -12,7 +12,6 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np
 import torch  # noqa: F401
 
-import oracle_lib as ol
 import sai2_primitives_perso_amd as pkg
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
@@ -41,7 +40,7 @@ def make(otg):
 
 if not ONLY_MOVING:
     c = make(False)
-    ol.load_inputs(c, inp)
+    pkg.workloads.load_inputs(c, inp)
     timed(c, 20)
     off = timed(c, 200)
     print(f"OTG off            : {off * 1e6:7.1f} us/step  {B / off / 1e9:.2f} G ticks/s")
