@@ -195,6 +195,9 @@ public:
 		_cfg.use_velocity_saturation = 0;
 		syncConfig();
 	}
+	bool getVelocitySaturationEnabled() const { return _cfg.use_velocity_saturation != 0; }
+	double getBoundedInertiaEstimateThreshold() const { return _cfg.bie_threshold; }
+	inline void resetIntegrators();
 	// JointTask.h:294-324 — internal OTG (on by default, acceleration-limited: JointTask.h:38-41)
 	void enableInternalOtgAccelerationLimited(const double max_velocity, const double max_acceleration) {
 		if (max_velocity <= 0)
@@ -360,6 +363,49 @@ public:
 		_cfg.s_max = s_max;
 		syncConfig();
 	}
+	void setSingularityHandlingGains(const double kp_type_1, const double kv_type_1, const double kv_type_2) {	// MotionForceTask.h:748-753
+		_cfg.kp_type_1 = kp_type_1, _cfg.kv_type_1 = kv_type_1, _cfg.kv_type_2 = kv_type_2;
+		syncConfig();
+	}
+	void disableSingularityHandling() {
+		_cfg.enforce_handling_strategy = 0;
+		syncConfig();
+	}
+	// MotionForceTask.h:330-356
+	void setFeedforwardForceGain(const double kff_force) {
+		_cfg.kff_force = kff_force;
+		syncConfig();
+	}
+	double getFeedforwardForceGain() const { return _cfg.kff_force; }
+	void setFeedforwardmomentGain(const double kff_moment) {
+		_cfg.kff_moment = kff_moment;
+		syncConfig();
+	}
+	double getFeedforwardmomentGain() const { return _cfg.kff_moment; }
+	void setMaxForceControlFeedbackOutput(const double v) {
+		_cfg.max_force_feedback = v;
+		syncConfig();
+	}
+	double getMaxForceControlFeedbackOutput() const { return _cfg.max_force_feedback; }
+	void setMaxMomentControlFeedbackOutput(const double v) {
+		_cfg.max_moment_feedback = v;
+		syncConfig();
+	}
+	double getMaxMomentControlFeedbackOutput() const { return _cfg.max_moment_feedback; }
+	// _T_control_to_sensor (MotionForceTask.cpp:794-803), given directly in the control frame
+	void setForceSensorFrame(const double sensor_pos_in_control_frame[3], const double* sensor_rot_in_control_frame = nullptr) {
+		for (int i = 0; i < 3; i++) _cfg.sensor_pos[i] = sensor_pos_in_control_frame[i];
+		for (int i = 0; i < 9; i++) _cfg.sensor_rot[i] = sensor_rot_in_control_frame ? sensor_rot_in_control_frame[i] : (i % 4 == 0 ? 1.0 : 0.0);
+		syncConfig();
+	}
+	int getForceSpaceDimension() const { return _cfg.force_space_dimension; }
+	int getMomentSpaceDimension() const { return _cfg.moment_space_dimension; }
+	bool getVelocitySaturationEnabled() const { return _cfg.use_velocity_saturation != 0; }
+	double getBoundedInertiaEstimateThreshold() const { return _cfg.bie_threshold; }
+	// MotionForceTask.cpp:988-1001
+	inline void resetIntegrators();
+	inline void resetIntegratorsLinear();
+	inline void resetIntegratorsAngular();
 	void enforceType1Strategy(const bool on = true) {
 		_cfg.enforce_type_1_strategy = on;
 		syncConfig();
@@ -521,6 +567,18 @@ private:
 	Batch _tau;
 };
 
+inline void JointTask::resetIntegrators() {
+	if (_owner) detail::check(_owner->ctx(), sai2b_reset_integrators(_owner->ctx(), _index, 0));
+}
+inline void MotionForceTask::resetIntegrators() {
+	if (_owner) detail::check(_owner->ctx(), sai2b_reset_integrators(_owner->ctx(), _index, 0));
+}
+inline void MotionForceTask::resetIntegratorsLinear() {
+	if (_owner) detail::check(_owner->ctx(), sai2b_reset_integrators(_owner->ctx(), _index, 1));
+}
+inline void MotionForceTask::resetIntegratorsAngular() {
+	if (_owner) detail::check(_owner->ctx(), sai2b_reset_integrators(_owner->ctx(), _index, 2));
+}
 inline Batch JointTask::desired(int which) const {
 	if (!_owner) throw std::invalid_argument("task is not attached to a RobotController");
 	Batch out((size_t)_cfg.task_dof * B());

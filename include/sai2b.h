@@ -289,6 +289,11 @@ int sai2b_get_state(sai2b_ctx* ctx, double* q, double* dq);
  * jointGravityVector of sai2-model) */
 int sai2b_get_bias(sai2b_ctx* ctx, int with_gravity, double* bias);
 
+/* MotionForceTask::resetIntegrators / resetIntegratorsLinear / resetIntegratorsAngular
+ * (MotionForceTask.cpp:988-1001) and JointTask::resetIntegrators: which = 0 all, 1 linear (position
+ * and force integrals), 2 angular (orientation and moment integrals); JointTask: any value. */
+int sai2b_reset_integrators(sai2b_ctx* ctx, int task, int which);
+
 /* Desired state the control law tracked in the last torque computation: the goal, or with the
  * internal OTG on its next state (JointTask::getDesiredPosition/Velocity/Acceleration,
  * JointTask.h:182-198; MotionForceTask::getDesired*). Host arrays, SoA [rows][B]; any may be NULL.

@@ -1744,6 +1744,22 @@ int oracle_get_bias(oracle_ctx* c, int with_gravity, double* out) {
 	}
 	return 0;
 }
+/* MotionForceTask::resetIntegrators* (MotionForceTask.cpp:988-1001), JointTask::resetIntegrators */
+int oracle_reset_integrators(oracle_ctx* c, int task, int which) {
+	if (task < 0 || task >= c->T) return fail("bad task");
+	for (int b = 0; b < c->B; b++) {
+		if (c->jt[task]) {
+			for (int i = 0; i < N7; i++) c->jt[task][b].integ[i] = 0;
+		} else {
+			mft_t* s = &c->mft[task][b];
+			for (int i = 0; i < 3; i++) {
+				if (which == 0 || which == 1) s->integ_pos[i] = s->integ_f[i] = 0;
+				if (which == 0 || which == 2) s->integ_ori[i] = s->integ_m[i] = 0;
+			}
+		}
+	}
+	return 0;
+}
 int oracle_get_jt_desired(oracle_ctx* c, int task, double* q, double* dq, double* ddq) {
 	if (task < 0 || task >= c->T || !c->jt[task]) return fail("not a JointTask");
 	const int k0 = c->cfg[task].task_dof;

@@ -88,6 +88,7 @@ int oracle_get_mft_task_forces(oracle_ctx* ctx, int task, double* F_unit, double
 int oracle_sim_step(oracle_ctx* ctx, const double* tau, double dt, int substeps, int with_gravity);
 int oracle_get_state(oracle_ctx* ctx, double* q, double* dq);
 int oracle_get_bias(oracle_ctx* ctx, int with_gravity, double* bias);
+int oracle_reset_integrators(oracle_ctx* ctx, int task, int which);
 /* desired state of the last computeTorques = goal, or the internal OTG's next state
  * (JointTask.h:182-198 getDesired*, MotionForceTask.h getDesired*); any pointer may be NULL */
 int oracle_get_jt_desired(oracle_ctx* ctx, int task, double* q, double* dq, double* ddq);

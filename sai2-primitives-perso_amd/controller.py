@@ -269,6 +269,10 @@ class Controller:
         self._rc(self.lib.sai2b_get_mft_task_forces(self.h, task, C.c_void_p(fu.ctypes.data), C.c_void_p(ff.ctypes.data)))
         return fu, ff
 
+    def reset_integrators(self, task, which=0):
+        """0 all, 1 linear (position / force), 2 angular (orientation / moment); JointTask: all"""
+        self._rc(self.lib.sai2b_reset_integrators(self.h, task, int(which)))
+
     # -- simulation harness
     def sim_step(self, tau=None, dt=0.001, substeps=1, with_gravity=False):
         """one control period of rigid-body dynamics under `tau` (None = the last computed torques; numpy
@@ -453,6 +457,23 @@ class JointTask(_TaskBase):
     def disableVelocitySaturation(self):
         self._cfg.use_velocity_saturation = 0
         self._sync_cfg()
+
+    def getGains(self):
+        k0 = self._cfg.task_dof
+        return [(self._cfg.kp[i], self._cfg.kv[i], self._cfg.ki[i]) for i in range(k0)]
+
+    def getTaskDof(self):
+        return self._cfg.task_dof
+
+    def getVelocitySaturationEnabled(self):
+        return bool(self._cfg.use_velocity_saturation)
+
+    def getBoundedInertiaEstimateThreshold(self):
+        return self._cfg.bie_threshold
+
+    def resetIntegrators(self):
+        rc, idx = self._require_owner()
+        rc._ctrl.reset_integrators(idx)
 
     def enableInternalOtgAccelerationLimited(self, max_velocity, max_acceleration):
         """JointTask.cpp:360-381 (scalars or per-task-dof vectors)"""
@@ -673,6 +694,87 @@ class MotionForceTask(_TaskBase):
     def setSingularityHandlingBounds(self, s_min, s_max):
         self._cfg.s_min, self._cfg.s_max = float(s_min), float(s_max)
         self._sync_cfg()
+
+    def setSingularityHandlingGains(self, kp_type_1, kv_type_1, kv_type_2):
+        """MotionForceTask.h:748-753"""
+        self._cfg.kp_type_1, self._cfg.kv_type_1, self._cfg.kv_type_2 = float(kp_type_1), float(kv_type_1), float(kv_type_2)
+        self._sync_cfg()
+
+    def enableSingularityHandling(self):
+        self._cfg.enforce_handling_strategy = 1
+        self._sync_cfg()
+
+    def disableSingularityHandling(self):
+        self._cfg.enforce_handling_strategy = 0
+        self._sync_cfg()
+
+    def setFeedforwardForceGain(self, kff):
+        self._cfg.kff_force = float(kff)
+        self._sync_cfg()
+
+    def getFeedforwardForceGain(self):
+        return self._cfg.kff_force
+
+    def setFeedforwardmomentGain(self, kff):
+        self._cfg.kff_moment = float(kff)
+        self._sync_cfg()
+
+    def getFeedforwardmomentGain(self):
+        return self._cfg.kff_moment
+
+    def setMaxForceControlFeedbackOutput(self, v):
+        self._cfg.max_force_feedback = float(v)
+        self._sync_cfg()
+
+    def getMaxForceControlFeedbackOutput(self):
+        return self._cfg.max_force_feedback
+
+    def setMaxMomentControlFeedbackOutput(self, v):
+        self._cfg.max_moment_feedback = float(v)
+        self._sync_cfg()
+
+    def getMaxMomentControlFeedbackOutput(self):
+        return self._cfg.max_moment_feedback
+
+    def setForceSensorFrame(self, sensor_pos_in_control_frame, sensor_rot_in_control_frame=None):
+        """_T_control_to_sensor (MotionForceTask.cpp:794-803), given directly in the control frame"""
+        p = np.asarray(sensor_pos_in_control_frame, dtype=float)
+        R = np.eye(3) if sensor_rot_in_control_frame is None else np.asarray(sensor_rot_in_control_frame, dtype=float)
+        for i in range(3):
+            self._cfg.sensor_pos[i] = p[i]
+        for i in range(9):
+            self._cfg.sensor_rot[i] = R.ravel()[i]
+        self._sync_cfg()
+
+    def getForceSpaceDimension(self):
+        return self._cfg.force_space_dimension
+
+    def getMomentSpaceDimension(self):
+        return self._cfg.moment_space_dimension
+
+    def getPosControlGains(self):
+        return [(self._cfg.kp_pos[i], self._cfg.kv_pos[i], self._cfg.ki_pos[i]) for i in range(3)]
+
+    def getOriControlGains(self):
+        return [(self._cfg.kp_ori[i], self._cfg.kv_ori[i], self._cfg.ki_ori[i]) for i in range(3)]
+
+    def getVelocitySaturationEnabled(self):
+        return bool(self._cfg.use_velocity_saturation)
+
+    def getBoundedInertiaEstimateThreshold(self):
+        return self._cfg.bie_threshold
+
+    def resetIntegrators(self):
+        rc, idx = self._require_owner()
+        rc._ctrl.reset_integrators(idx, 0)
+
+    def resetIntegratorsLinear(self):
+        rc, idx = self._require_owner()
+        rc._ctrl.reset_integrators(idx, 1)
+
+    def resetIntegratorsAngular(self):
+        rc, idx = self._require_owner()
+        rc._ctrl.reset_integrators(idx, 2)
 
     def getUnitMassForce(self):
         rc, idx = self._require_owner()

@@ -959,6 +959,27 @@ extern "C" int sai2b_get_bias(sai2b_ctx* ctx, int with_gravity, double* bias) {
 	return fetch_rows(ctx, ctx->sim_tau, 0, N, bias);
 }
 
+extern "C" int sai2b_reset_integrators(sai2b_ctx* ctx, int task, int which) {
+	if (!ctx || task < 0 || task >= ctx->T) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_reset_integrators: bad arguments");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	double* S = ctx->h_params.task[task].state;
+	const size_t B = ctx->B, row = B * sizeof(double);
+	if (ctx->cfg[task].type == SAI2B_JOINT_TASK) {
+		HIP_TRY(ctx, hipMemsetAsync(S, 0, row * ctx->cfg[task].task_dof, ctx->stream));
+		return SAI2B_OK;
+	}
+	// MFT state rows: integral of position 0-2, orientation 3-5, force 6-8, moment 9-11
+	if (which == 0 || which == 1) {
+		HIP_TRY(ctx, hipMemsetAsync(S, 0, row * 3, ctx->stream));
+		HIP_TRY(ctx, hipMemsetAsync(S + 6 * B, 0, row * 3, ctx->stream));
+	}
+	if (which == 0 || which == 2) {
+		HIP_TRY(ctx, hipMemsetAsync(S + 3 * B, 0, row * 3, ctx->stream));
+		HIP_TRY(ctx, hipMemsetAsync(S + 9 * B, 0, row * 3, ctx->stream));
+	}
+	return SAI2B_OK;
+}
+
 extern "C" int sai2b_get_jt_desired(sai2b_ctx* ctx, int task, double* q, double* dq, double* ddq) {
 	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
 	if (task < 0 || task >= ctx->T || ctx->cfg[task].type != SAI2B_JOINT_TASK)

@@ -64,6 +64,7 @@ def lib():
     L.oracle_get_jt_desired.argtypes = [vp, i, vp, vp, vp]
     L.oracle_get_mft_desired.argtypes = [vp, i] + [vp] * 6
     L.oracle_get_otg_status.argtypes = [vp, i, vp, vp]
+    L.oracle_reset_integrators.argtypes = [vp, i, i]
     L.oracle_sim_step.argtypes = [vp, vp, d, i, i]
     L.oracle_get_state.argtypes = [vp, vp, vp]
     L.oracle_get_bias.argtypes = [vp, i, vp]
@@ -282,6 +283,9 @@ class Oracle:
         assert self.L.oracle_get_jt_inertia(self.h, task, _ptr(a), _ptr(b)) == 0
         return a, b
 
+
+    def reset_integrators(self, task, which=0):
+        assert self.L.oracle_reset_integrators(self.h, task, which) == 0
 
     def sim_step(self, tau, dt=0.001, substeps=1, with_gravity=False):
         tau = _arr(tau, (DOF, self.B))

@@ -472,3 +472,29 @@ def test_modified_robot_model_runtime_constants():
         e = _err(tau_g, tau_o)
         assert e[ro == 6].max() < 10 * TOL, e[ro == 6].max()
         assert e.max() < 1e-6
+
+
+def test_reset_integrators_and_config_accessors():
+    """resetIntegrators / resetIntegratorsLinear / resetIntegratorsAngular (MotionForceTask.cpp:988-1001)
+    and the run-time setters that only touch batch-uniform parameters, against the oracle"""
+    B = 64
+    inp = pkg.workloads.make_inputs(3, B=B, seed=17)
+    opts = [{"ki_pos": 5.0, "ki_ori": 3.0}, {"ki": 2.0}]
+    o, g = _pair(inp, opts, introspection=False)
+    for c in (o, g):
+        ol.load_inputs(c, inp)
+    for step in range(9):
+        if step == 3:
+            for c in (o, g):
+                c.reset_integrators(0, 1)  # linear only
+        if step == 5:
+            for c in (o, g):
+                c.reset_integrators(0, 2)
+                c.reset_integrators(1, 0)
+        if step == 7:  # gains of the singularity handler and force-loop limits change at run time
+            for c in (o, g):
+                cfg = c.tasks[0]
+                cfg.kp_type_1, cfg.kv_type_1, cfg.kv_type_2 = 40.0, 12.0, 4.0
+                cfg.kff_force, cfg.max_force_feedback = 0.9, 15.0
+                c.update_task_config(0, cfg)
+        assert _err(g.tick(), o.tick()).max() < TOL, step
