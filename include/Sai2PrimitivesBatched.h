@@ -402,6 +402,19 @@ public:
 	int getMomentSpaceDimension() const { return _cfg.moment_space_dimension; }
 	bool getVelocitySaturationEnabled() const { return _cfg.use_velocity_saturation != 0; }
 	double getBoundedInertiaEstimateThreshold() const { return _cfg.bie_threshold; }
+	// observers between ticks (MotionForceTask.h:121-165,214-247; MotionForceTask.cpp:540-579); which: 0 position,
+	// 1 orientation, 2 sensed force, 3 sensed moment (world frame), 4 position error, 5 orientation error
+	inline Batch getCurrentPosition() const;
+	inline Batch getCurrentOrientation() const;
+	inline Batch getSensedForceControlWorldFrame() const;
+	inline Batch getSensedMomentControlWorldFrame() const;
+	inline Batch getPositionError() const;
+	inline Batch getOrientationError() const;
+	// one flag per robot
+	inline std::vector<bool> goalPositionReached(const double tolerance) const;
+	inline std::vector<bool> goalOrientationReached(const double tolerance) const;
+	inline Batch getGoalPosition() const;
+	inline Batch getGoalOrientation() const;
 	// MotionForceTask.cpp:988-1001
 	inline void resetIntegrators();
 	inline void resetIntegratorsLinear();
@@ -420,6 +433,7 @@ public:
 protected:
 	inline void flushGoals() override;
 	inline Batch desired(int which) const;
+	inline Batch status(int which) const;
 	void set(Batch& dst, const Batch& v, size_t rows, const char* what) {
 		checkRows(v, rows, what);
 		dst = v;
@@ -567,6 +581,45 @@ private:
 	Batch _tau;
 };
 
+inline Batch MotionForceTask::status(int which) const {
+	if (!_owner) throw std::invalid_argument("task is not attached to a RobotController");
+	const size_t rows[8] = {3, 9, 3, 3, 3, 3, 1, 1};
+	Batch out(rows[which] * B());
+	double* p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	p[which] = out.data();
+	detail::check(_owner->ctx(), sai2b_get_mft_status(_owner->ctx(), _index, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]));
+	return out;
+}
+inline Batch MotionForceTask::getCurrentPosition() const { return status(0); }
+inline Batch MotionForceTask::getCurrentOrientation() const { return status(1); }
+inline Batch MotionForceTask::getSensedForceControlWorldFrame() const { return status(2); }
+inline Batch MotionForceTask::getSensedMomentControlWorldFrame() const { return status(3); }
+inline Batch MotionForceTask::getPositionError() const { return status(4); }
+inline Batch MotionForceTask::getOrientationError() const { return status(5); }
+inline std::vector<bool> MotionForceTask::goalPositionReached(const double tolerance) const {
+	const Batch n = status(6);
+	std::vector<bool> r(n.size());
+	for (size_t i = 0; i < n.size(); i++) r[i] = n[i] < tolerance;
+	return r;
+}
+inline std::vector<bool> MotionForceTask::goalOrientationReached(const double tolerance) const {
+	const Batch n = status(7);
+	std::vector<bool> r(n.size());
+	for (size_t i = 0; i < n.size(); i++) r[i] = n[i] < tolerance;
+	return r;
+}
+inline Batch MotionForceTask::getGoalPosition() const {
+	if (!_owner) throw std::invalid_argument("task is not attached to a RobotController");
+	Batch out(3 * B());
+	detail::check(_owner->ctx(), sai2b_get_mft_goals(_owner->ctx(), _index, out.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+	return out;
+}
+inline Batch MotionForceTask::getGoalOrientation() const {
+	if (!_owner) throw std::invalid_argument("task is not attached to a RobotController");
+	Batch out(9 * B());
+	detail::check(_owner->ctx(), sai2b_get_mft_goals(_owner->ctx(), _index, nullptr, out.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+	return out;
+}
 inline void JointTask::resetIntegrators() {
 	if (_owner) detail::check(_owner->ctx(), sai2b_reset_integrators(_owner->ctx(), _index, 0));
 }

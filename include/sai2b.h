@@ -289,6 +289,20 @@ int sai2b_get_state(sai2b_ctx* ctx, double* q, double* dq);
  * jointGravityVector of sai2-model) */
 int sai2b_get_bias(sai2b_ctx* ctx, int with_gravity, double* bias);
 
+/* Observers the reference's callers use between ticks, computed from the state and goal buffers as
+ * they are now (the reference caches them at the last computeTorques): MotionForceTask::
+ * getCurrentPosition / getCurrentOrientation (MotionForceTask.h:121-140), getSensedForce/
+ * MomentControlWorldFrame (:154-165), getPositionError / getOrientationError
+ * (MotionForceTask.cpp:540-546), and the norms sqrt(e^T sigma e) that goalPositionReached /
+ * goalOrientationReached compare with their tolerance (:548-579). Host arrays [rows][B], any NULL. */
+int sai2b_get_mft_status(sai2b_ctx* ctx, int task, double* pos, double* rot, double* sensed_force_world,
+						 double* sensed_moment_world, double* pos_error, double* ori_error,
+						 double* pos_error_norm, double* ori_error_norm);
+/* getGoalPosition ... getGoalMoment (MotionForceTask.h:214-247,  JointTask.h:144-160) */
+int sai2b_get_mft_goals(sai2b_ctx* ctx, int task, double* pos, double* rot, double* lin_vel, double* ang_vel,
+						double* lin_acc, double* ang_acc, double* force, double* moment);
+int sai2b_get_jt_goals(sai2b_ctx* ctx, int task, double* q, double* dq, double* ddq);
+
 /* MotionForceTask::resetIntegrators / resetIntegratorsLinear / resetIntegratorsAngular
  * (MotionForceTask.cpp:988-1001) and JointTask::resetIntegrators: which = 0 all, 1 linear (position
  * and force integrals), 2 angular (orientation and moment integrals); JointTask: any value. */

@@ -1744,6 +1744,46 @@ int oracle_get_bias(oracle_ctx* c, int with_gravity, double* out) {
 	}
 	return 0;
 }
+/* observers between ticks (MotionForceTask.h:121-165, MotionForceTask.cpp:540-579), from the current
+ * state and goals; out arrays [rows][B], any NULL */
+int oracle_get_mft_status(oracle_ctx* c, int task, double* pos, double* rot, double* fw, double* mw, double* pe,
+						  double* oe_out, double* pn, double* on) {
+	if (task < 0 || task >= c->T || !c->mft[task]) return fail("not a MotionForceTask");
+	const sai2b_task_config* t = &c->cfg[task];
+	for (int b = 0; b < c->B; b++) {
+		ensure_model(c, b);
+		const robot_t* r = &c->robots[b];
+		const mft_t* s = &c->mft[task][b];
+		double x[3], R[9], sf[9], sp[9], sm[9], so[9], e[3], oe[3], se[3], soe[3];
+		frame_pose(t, r->Rl, r->pl, x, R);
+		sigma_pair(t->partial_projection, 0, t->force_space_dimension, t->force_axis, R, t->parametrization_in_compliant_frame, sf, sp);
+		sigma_pair(t->partial_projection, 1, t->moment_space_dimension, t->moment_axis, R, t->parametrization_in_compliant_frame, sm, so);
+		for (int i = 0; i < 3; i++) e[i] = s->g_pos[i] - x[i];
+		orientation_error(s->g_rot, R, oe);
+		mv3(sp, e, se);
+		mv3(so, oe, soe);
+		double fs_c[3], ms_c[3], tmp[3], fs_w[3], ms_w[3];
+		mv3(t->sensor_rot, s->sens_f, fs_c);
+		mv3(t->sensor_rot, s->sens_m, ms_c);
+		cross3(t->sensor_pos, fs_c, tmp);
+		for (int i = 0; i < 3; i++) ms_c[i] += tmp[i];
+		mv3(R, fs_c, fs_w);
+		mv3(R, ms_c, ms_w);
+		for (int i = 0; i < 3; i++) {
+			if (pos) pos[i * c->B + b] = x[i];
+			if (fw) fw[i * c->B + b] = fs_w[i];
+			if (mw) mw[i * c->B + b] = ms_w[i];
+			if (pe) pe[i * c->B + b] = se[i];
+			if (oe_out) oe_out[i * c->B + b] = soe[i];
+		}
+		if (rot)
+			for (int i = 0; i < 9; i++) rot[i * c->B + b] = R[i];
+		double a = e[0] * se[0] + e[1] * se[1] + e[2] * se[2], d = oe[0] * soe[0] + oe[1] * soe[1] + oe[2] * soe[2];
+		if (pn) pn[b] = sqrt(a > 0 ? a : 0);
+		if (on) on[b] = sqrt(d > 0 ? d : 0);
+	}
+	return 0;
+}
 /* MotionForceTask::resetIntegrators* (MotionForceTask.cpp:988-1001), JointTask::resetIntegrators */
 int oracle_reset_integrators(oracle_ctx* c, int task, int which) {
 	if (task < 0 || task >= c->T) return fail("bad task");

@@ -88,6 +88,9 @@ int oracle_get_mft_task_forces(oracle_ctx* ctx, int task, double* F_unit, double
 int oracle_sim_step(oracle_ctx* ctx, const double* tau, double dt, int substeps, int with_gravity);
 int oracle_get_state(oracle_ctx* ctx, double* q, double* dq);
 int oracle_get_bias(oracle_ctx* ctx, int with_gravity, double* bias);
+int oracle_get_mft_status(oracle_ctx* ctx, int task, double* pos, double* rot, double* sensed_force_world,
+						  double* sensed_moment_world, double* pos_error, double* ori_error, double* pos_error_norm,
+						  double* ori_error_norm);
 int oracle_reset_integrators(oracle_ctx* ctx, int task, int which);
 /* desired state of the last computeTorques = goal, or the internal OTG's next state
  * (JointTask.h:182-198 getDesired*, MotionForceTask.h getDesired*); any pointer may be NULL */

@@ -196,6 +196,9 @@ EXPORTS = [
     "sai2b_get_task_torques",
     "sai2b_get_mft_singularity",
     "sai2b_get_mft_task_forces",
+    "sai2b_get_mft_status",
+    "sai2b_get_mft_goals",
+    "sai2b_get_jt_goals",
     "sai2b_reset_integrators",
     "sai2b_sim_step",
     "sai2b_get_state",
@@ -269,6 +272,9 @@ def load_library():
     lib.sai2b_get_task_torques.argtypes = [vp, _i, vp]
     lib.sai2b_get_mft_singularity.argtypes = [vp, _i, vp, vp, vp]
     lib.sai2b_get_mft_task_forces.argtypes = [vp, _i, vp, vp]
+    lib.sai2b_get_mft_status.argtypes = [vp, _i] + [vp] * 8
+    lib.sai2b_get_mft_goals.argtypes = [vp, _i] + [vp] * 8
+    lib.sai2b_get_jt_goals.argtypes = [vp, _i, vp, vp, vp]
     lib.sai2b_reset_integrators.argtypes = [vp, _i, _i]
     lib.sai2b_sim_step.argtypes = [vp, vp, _i, _d, _i, _i]
     lib.sai2b_get_state.argtypes = [vp, vp, vp]

@@ -269,6 +269,27 @@ class Controller:
         self._rc(self.lib.sai2b_get_mft_task_forces(self.h, task, C.c_void_p(fu.ctypes.data), C.c_void_p(ff.ctypes.data)))
         return fu, ff
 
+    def get_mft_status(self, task):
+        """dict: pos [3,B], rot [9,B], sensed_force / sensed_moment (world frame) [3,B], pos_error, ori_error [3,B],
+        pos_error_norm, ori_error_norm [B] (what goalPositionReached / goalOrientationReached compare)"""
+        B = self.B
+        names = ("pos", "rot", "sensed_force", "sensed_moment", "pos_error", "ori_error", "pos_error_norm", "ori_error_norm")
+        out = [np.empty((r, B)) for r in (3, 9, 3, 3, 3, 3)] + [np.empty(B), np.empty(B)]
+        self._rc(self.lib.sai2b_get_mft_status(self.h, task, *[C.c_void_p(x.ctypes.data) for x in out]))
+        return dict(zip(names, out))
+
+    def get_mft_goals(self, task):
+        B = self.B
+        out = [np.empty((r, B)) for r in (3, 9, 3, 3, 3, 3, 3, 3)]
+        self._rc(self.lib.sai2b_get_mft_goals(self.h, task, *[C.c_void_p(x.ctypes.data) for x in out]))
+        return tuple(out)
+
+    def get_jt_goals(self, task):
+        k0 = self.tasks[task].task_dof
+        out = [np.empty((k0, self.B)) for _ in range(3)]
+        self._rc(self.lib.sai2b_get_jt_goals(self.h, task, *[C.c_void_p(x.ctypes.data) for x in out]))
+        return tuple(out)
+
     def reset_integrators(self, task, which=0):
         """0 all, 1 linear (position / force), 2 angular (orientation / moment); JointTask: all"""
         self._rc(self.lib.sai2b_reset_integrators(self.h, task, int(which)))
@@ -457,6 +478,29 @@ class JointTask(_TaskBase):
     def disableVelocitySaturation(self):
         self._cfg.use_velocity_saturation = 0
         self._sync_cfg()
+
+    def getGoalPosition(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_jt_goals(idx)[0]
+
+    def getGoalVelocity(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_jt_goals(idx)[1]
+
+    def getGoalAcceleration(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_jt_goals(idx)[2]
+
+    def getCurrentPosition(self):
+        """S q (JointTask.h:130), from the controller's state buffer"""
+        rc, idx = self._require_owner()
+        S = np.array(self._cfg.joint_selection[: self._cfg.task_dof * DOF]).reshape(self._cfg.task_dof, DOF)
+        return S @ rc._ctrl.get_state()[0]
+
+    def getCurrentVelocity(self):
+        rc, idx = self._require_owner()
+        S = np.array(self._cfg.joint_selection[: self._cfg.task_dof * DOF]).reshape(self._cfg.task_dof, DOF)
+        return S @ rc._ctrl.get_state()[1]
 
     def getGains(self):
         k0 = self._cfg.task_dof
@@ -694,6 +738,51 @@ class MotionForceTask(_TaskBase):
     def setSingularityHandlingBounds(self, s_min, s_max):
         self._cfg.s_min, self._cfg.s_max = float(s_min), float(s_max)
         self._sync_cfg()
+
+    def _status(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_status(idx)
+
+    def getCurrentPosition(self):
+        return self._status()["pos"]
+
+    def getCurrentOrientation(self):
+        return self._status()["rot"]
+
+    def getSensedForceControlWorldFrame(self):
+        return self._status()["sensed_force"]
+
+    def getSensedMomentControlWorldFrame(self):
+        return self._status()["sensed_moment"]
+
+    def getPositionError(self):
+        return self._status()["pos_error"]
+
+    def getOrientationError(self):
+        return self._status()["ori_error"]
+
+    def goalPositionReached(self, tolerance):
+        """per robot (MotionForceTask.cpp:548-563)"""
+        return self._status()["pos_error_norm"] < tolerance
+
+    def goalOrientationReached(self, tolerance):
+        return self._status()["ori_error_norm"] < tolerance
+
+    def getGoalPosition(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_goals(idx)[0]
+
+    def getGoalOrientation(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_goals(idx)[1]
+
+    def getGoalForce(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_goals(idx)[6]
+
+    def getGoalMoment(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_goals(idx)[7]
 
     def setSingularityHandlingGains(self, kp_type_1, kv_type_1, kv_type_2):
         """MotionForceTask.h:748-753"""

@@ -45,6 +45,7 @@ struct sai2b_ctx {
 	DevParams* d_params = nullptr;
 	hipStream_t stream = nullptr;
 	double *q = nullptr, *dq = nullptr, *tau = nullptr;
+	double* status_buf = nullptr;  // [26][B] scratch of sai2b_get_mft_status
 	double* sim_tau = nullptr;	// staging for host torques / bias read-back of the simulation harness
 	std::vector<void*> allocs;
 	long long launches = 0, ticks = 0;
@@ -957,6 +958,49 @@ extern "C" int sai2b_get_bias(sai2b_ctx* ctx, int with_gravity, double* bias) {
 	if (sai2b_launch_sim(ctx->d_params, ctx->B, nullptr, 0.0, 1, with_gravity, ctx->sim_tau, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "simulation launch failed");
 	return fetch_rows(ctx, ctx->sim_tau, 0, N, bias);
+}
+
+extern "C" int sai2b_get_mft_status(sai2b_ctx* ctx, int task, double* pos, double* rot, double* sensed_force_world,
+									double* sensed_moment_world, double* pos_error, double* ori_error, double* pos_error_norm,
+									double* ori_error_norm) {
+	int rc = mft_task_check(ctx, task, "sai2b_get_mft_status");
+	if (rc) return rc;
+	if ((rc = upload_params(ctx))) return rc;
+	if (!ctx->status_buf && (rc = dev_alloc(ctx, &ctx->status_buf, 26 * (size_t)ctx->B))) return rc;
+	if (sai2b_launch_mft_status(ctx->d_params, ctx->B, task, ctx->status_buf, ctx->stream))
+		return set_error(ctx, SAI2B_RUNTIME_ERROR, "status launch failed");
+	const double* S = ctx->status_buf;
+	if ((rc = fetch_rows(ctx, S, 0, 3, pos))) return rc;
+	if ((rc = fetch_rows(ctx, S, 3, 9, rot))) return rc;
+	if ((rc = fetch_rows(ctx, S, 12, 3, sensed_force_world))) return rc;
+	if ((rc = fetch_rows(ctx, S, 15, 3, sensed_moment_world))) return rc;
+	if ((rc = fetch_rows(ctx, S, 18, 3, pos_error))) return rc;
+	if ((rc = fetch_rows(ctx, S, 21, 3, ori_error))) return rc;
+	if ((rc = fetch_rows(ctx, S, 24, 1, pos_error_norm))) return rc;
+	return fetch_rows(ctx, S, 25, 1, ori_error_norm);
+}
+extern "C" int sai2b_get_mft_goals(sai2b_ctx* ctx, int task, double* pos, double* rot, double* lin_vel, double* ang_vel,
+								   double* lin_acc, double* ang_acc, double* force, double* moment) {
+	int rc = mft_task_check(ctx, task, "sai2b_get_mft_goals");
+	if (rc) return rc;
+	const double* G = ctx->h_params.task[task].goals;
+	double* dst[8] = {pos, rot, lin_vel, ang_vel, lin_acc, ang_acc, force, moment};
+	const size_t row0[8] = {0, 3, 12, 15, 18, 21, 24, 27}, rows[8] = {3, 9, 3, 3, 3, 3, 3, 3};
+	for (int k = 0; k < 8; k++)
+		if ((rc = fetch_rows(ctx, G, row0[k], rows[k], dst[k]))) return rc;
+	return SAI2B_OK;
+}
+extern "C" int sai2b_get_jt_goals(sai2b_ctx* ctx, int task, double* q, double* dq, double* ddq) {
+	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	if (task < 0 || task >= ctx->T || ctx->cfg[task].type != SAI2B_JOINT_TASK)
+		return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_get_jt_goals: task is not a JointTask");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const double* G = ctx->h_params.task[task].goals;
+	const size_t k0 = ctx->cfg[task].task_dof;
+	int rc;
+	if ((rc = fetch_rows(ctx, G, 0, k0, q))) return rc;
+	if ((rc = fetch_rows(ctx, G, k0, k0, dq))) return rc;
+	return fetch_rows(ctx, G, 2 * k0, k0, ddq);
 }
 
 extern "C" int sai2b_reset_integrators(sai2b_ctx* ctx, int task, int which) {

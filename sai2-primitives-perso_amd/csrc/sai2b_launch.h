@@ -19,3 +19,5 @@ extern "C" int sai2b_launch_otg_reinit(const sai2b::DevParams* d_params, int B, 
 // simulation harness (sai2b_sim.hip): one control period of rigid-body dynamics, state updated in place
 extern "C" int sai2b_launch_sim(const sai2b::DevParams* d_params, int B, const double* tau, double dt, int substeps,
 								int with_gravity, double* dbg_bias, hipStream_t stream);
+// observers of a MotionForceTask between ticks: out [26][B] (rows in sai2b_sim.hip: mft_status_kernel)
+extern "C" int sai2b_launch_mft_status(const sai2b::DevParams* d_params, int B, int task, double* out, hipStream_t stream);

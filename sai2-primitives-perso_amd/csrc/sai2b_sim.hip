@@ -120,7 +120,64 @@ __global__ __launch_bounds__(64) void sim_kernel(const DevParams* __restrict__ P
 	}
 }
 
+// What the tasks' observers read between ticks (MotionForceTask.h:121-165: getCurrentPosition /
+// Orientation, getSensedForce/MomentControlWorldFrame; MotionForceTask.cpp:540-579: getPositionError,
+// getOrientationError, goalPositionReached, goalOrientationReached), computed from the state and goal
+// buffers as they are now. out [26][B]: position 3, orientation 9, sensed force 3 and moment 3 in the
+// world frame at the control point, sigma_position (goal - current) 3, sigma_orientation orientationError 3,
+// and the two scalar norms sqrt(e^T sigma e) the goal...Reached tests compare with their tolerance.
+__global__ __launch_bounds__(64) void mft_status_kernel(const DevParams* __restrict__ Pp, int task, real* __restrict__ out) {
+	const DevParams& P = *Pp;
+	const int B = P.B;
+	const int b = blockIdx.x * 64 + threadIdx.x;
+	if (b >= B) return;
+	const DevTask& t = P.task[task];
+	real q[N];
+	UNROLL for (int i = 0; i < N; i++) q[i] = ld(P.q, i, B, b);
+	Frames F;
+	fk(P.model, q, F);
+	real x[3], R[9];
+	frame_pose(t, F, x, R);
+	real sf[9], sp[9], sm[9], so[9];
+	sigma_pair(t, 0, t.fdim, t.faxis, R, sf, sp);
+	sigma_pair(t, 1, t.mdim, t.maxis, R, sm, so);
+	real gpos[3], grot[9], e[3], oe[3], se[3], soe[3];
+	UNROLL for (int k = 0; k < 3; k++) gpos[k] = ld(t.goals, k, B, b);
+	UNROLL for (int k = 0; k < 9; k++) grot[k] = ld(t.goals, 3 + k, B, b);
+	UNROLL for (int k = 0; k < 3; k++) e[k] = gpos[k] - x[k];
+	orientation_error(grot, R, oe);
+	mv3(sp, e, se);
+	mv3(so, oe, soe);
+	// sensed wrench at the control point, world frame (MotionForceTask.cpp:805-828)
+	real sfc[3], smc[3], fs_c[3], ms_c[3], tmp[3], fs_w[3], ms_w[3];
+	UNROLL for (int k = 0; k < 3; k++) {
+		sfc[k] = ld(t.sensed, k, B, b);
+		smc[k] = ld(t.sensed, 3 + k, B, b);
+	}
+	mv3(t.sensor_rot, sfc, fs_c);
+	mv3(t.sensor_rot, smc, ms_c);
+	cross3(t.sensor_pos, fs_c, tmp);
+	UNROLL for (int k = 0; k < 3; k++) ms_c[k] += tmp[k];
+	mv3(R, fs_c, fs_w);
+	mv3(R, ms_c, ms_w);
+	UNROLL for (int k = 0; k < 3; k++) {
+		st(out, k, B, b, x[k]);
+		st(out, 12 + k, B, b, fs_w[k]);
+		st(out, 15 + k, B, b, ms_w[k]);
+		st(out, 18 + k, B, b, se[k]);
+		st(out, 21 + k, B, b, soe[k]);
+	}
+	UNROLL for (int k = 0; k < 9; k++) st(out, 3 + k, B, b, R[k]);
+	st(out, 24, B, b, sqrt(fmax(e[0] * se[0] + e[1] * se[1] + e[2] * se[2], 0.0)));
+	st(out, 25, B, b, sqrt(fmax(oe[0] * soe[0] + oe[1] * soe[1] + oe[2] * soe[2], 0.0)));
+}
+
 }  // namespace sai2b
+
+extern "C" int sai2b_launch_mft_status(const sai2b::DevParams* d_params, int B, int task, double* out, hipStream_t stream) {
+	hipLaunchKernelGGL(sai2b::mft_status_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, d_params, task, out);
+	return hipGetLastError() == hipSuccess ? 0 : 1;
+}
 
 extern "C" int sai2b_launch_sim(const sai2b::DevParams* d_params, int B, const double* tau, double dt, int substeps,
 								int with_gravity, double* dbg_bias, hipStream_t stream) {

@@ -64,6 +64,7 @@ def lib():
     L.oracle_get_jt_desired.argtypes = [vp, i, vp, vp, vp]
     L.oracle_get_mft_desired.argtypes = [vp, i] + [vp] * 6
     L.oracle_get_otg_status.argtypes = [vp, i, vp, vp]
+    L.oracle_get_mft_status.argtypes = [vp, i] + [vp] * 8
     L.oracle_reset_integrators.argtypes = [vp, i, i]
     L.oracle_sim_step.argtypes = [vp, vp, d, i, i]
     L.oracle_get_state.argtypes = [vp, vp, vp]
@@ -283,6 +284,13 @@ class Oracle:
         assert self.L.oracle_get_jt_inertia(self.h, task, _ptr(a), _ptr(b)) == 0
         return a, b
 
+
+    def get_mft_status(self, task):
+        B = self.B
+        names = ("pos", "rot", "sensed_force", "sensed_moment", "pos_error", "ori_error", "pos_error_norm", "ori_error_norm")
+        out = [np.empty((r, B)) for r in (3, 9, 3, 3, 3, 3)] + [np.empty(B), np.empty(B)]
+        assert self.L.oracle_get_mft_status(self.h, task, *[_ptr(x) for x in out]) == 0
+        return dict(zip(names, out))
 
     def reset_integrators(self, task, which=0):
         assert self.L.oracle_reset_integrators(self.h, task, which) == 0

@@ -498,3 +498,39 @@ def test_reset_integrators_and_config_accessors():
                 cfg.kff_force, cfg.max_force_feedback = 0.9, 15.0
                 c.update_task_config(0, cfg)
         assert _err(g.tick(), o.tick()).max() < TOL, step
+
+
+def test_task_observers_between_ticks():
+    """getCurrentPosition/Orientation, sensed wrench in the world frame, position/orientation errors and
+    the goal...Reached norms (MotionForceTask.h:121-165, MotionForceTask.cpp:540-579), goal getters —
+    with a force-space parametrisation so that sigma_position is not the identity"""
+    B = 96
+    inp = pkg.workloads.make_inputs(3, B=B, seed=23)
+    opts = [{"force_space_dimension": 1, "moment_space_dimension": 2, "force_axis": (0, 0, 1), "moment_axis": (1, 0, 0),
+             "in_compliant_frame": True}, {}]
+    o, g = _pair(inp, opts, introspection=False)
+    rng = np.random.default_rng(1)
+    sf, sm = rng.normal(0, 5, (3, B)), rng.normal(0, 1, (3, B))
+    for c in (o, g):
+        ol.load_inputs(c, inp)
+        c.set_mft_sensed_wrench(0, sf, sm)
+        c.tick()
+    so, sg = o.get_mft_status(0), g.get_mft_status(0)
+    for k in so:
+        assert np.abs(so[k] - sg[k]).max() < 1e-12 * max(1.0, np.abs(so[k]).max()), k
+    assert sg["pos_error_norm"].max() > 1e-3  # the goals are away from the current pose
+    goals = g.get_mft_goals(0)
+    assert np.array_equal(goals[0], inp["mft0"]["pos"]) and np.array_equal(goals[1], inp["mft0"]["rot"])
+    assert np.array_equal(g.get_jt_goals(1)[0], inp["jt1"]["q"])
+    # facade spelling
+    robot = pkg.BatchedRobotModel(B)
+    robot.setQ(inp["q"])
+    robot.setDq(inp["dq"])
+    mft, jt = pkg.MotionForceTask(robot, task_name="ee"), pkg.JointTask(robot)
+    ctl = pkg.RobotController(robot, [mft, jt])
+    assert mft.goalPositionReached(1e-9).all() and mft.goalOrientationReached(1e-9).all()  # goals = current pose
+    mft.setGoalPosition(inp["mft0"]["pos"])
+    assert not mft.goalPositionReached(1e-4).any()
+    assert np.abs(mft.getCurrentPosition() - sg["pos"]).max() < 1e-12
+    assert np.array_equal(jt.getCurrentPosition(), inp["q"]) and np.array_equal(mft.getGoalPosition(), inp["mft0"]["pos"])
+    del ctl
