@@ -567,7 +567,8 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 		if ((rc = dev_alloc(ctx, &d.otg_desired, goal_rows * Bs))) return rc;
 		if ((rc = dev_alloc(ctx, &d.otg_state, (size_t)sai2b::OTG_ROWS * Bs))) return rc;
 		d.otg_epoch = 0.0;
-		d.law_goals = d.otg_on ? d.otg_desired : d.goals;
+		d.otg_out_is_desired = (tasks[t].type == SAI2B_JOINT_TASK && d.k0 == N) ? 1 : 0;
+		d.law_goals = d.otg_on ? (d.otg_out_is_desired ? d.otg_state + (size_t)sai2b::OTG_OUT * Bs : d.otg_desired) : d.goals;
 	}
 	for (int t = 0; t < n_tasks; t++)
 		if (tasks[t].type == SAI2B_MOTION_FORCE_TASK && tasks[t].passivity_enabled && (rc = popc_reinit(ctx, t))) return rc;
@@ -643,7 +644,8 @@ extern "C" int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_ta
 	d.dbg_tau = keep.dbg_tau, d.dbg_N = keep.dbg_N, d.dbg_sigma = keep.dbg_sigma, d.dbg_J = keep.dbg_J, d.dbg_pose = keep.dbg_pose;
 	d.dbg_F = keep.dbg_F;
 	d.otg_desired = keep.otg_desired, d.otg_state = keep.otg_state, d.otg_epoch = keep.otg_epoch;
-	d.law_goals = d.otg_on ? d.otg_desired : d.goals;
+	d.otg_out_is_desired = keep.otg_out_is_desired;
+	d.law_goals = d.otg_on ? (d.otg_out_is_desired ? d.otg_state + (size_t)sai2b::OTG_OUT * ctx->B : d.otg_desired) : d.goals;
 	ctx->params_dirty = true;
 	ctx->goals_dirty |= 1u << task;
 	// enableInternalOtgAccelerationLimited (JointTask.cpp:360-381, MotionForceTask.cpp:511-523) is

@@ -256,7 +256,7 @@ DI void sample_lane(const DevTask& t, bool cart, int n, int B, int b, Gen& g) {
 	}
 	if (cart)
 		store_desired_cart(t.otg_desired, B, b, g);
-	else
+	else if (!t.otg_out_is_desired)
 		store_desired_joints(t.otg_desired, n, B, b, g);
 }
 
@@ -347,7 +347,7 @@ DI void plan_group(const DevTask& t, bool cart, int n, int B, int b) {
 	}
 	if (cart) {
 		if (j < 3) st(t.otg_desired, j, B, b, g.np), st(t.otg_desired, 12 + j, B, b, g.nv), st(t.otg_desired, 18 + j, B, b, g.na);
-	} else if (active) {
+	} else if (active && !t.otg_out_is_desired) {
 		st(t.otg_desired, j, B, b, g.np), st(t.otg_desired, n + j, B, b, g.nv), st(t.otg_desired, 2 * n + j, B, b, g.na);
 	}
 }
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(64) void otg_reinit_kernel(const DevParams* __restr
 				UNROLL for (int d = 0; d < MD; d++) g.in.ca[d] = 0;
 			}
 			store_state(S, n, false, B, b, g);
-			store_desired_joints(tk.otg_desired, n, B, b, g);
+			if (!tk.otg_out_is_desired) store_desired_joints(tk.otg_desired, n, B, b, g);
 		} else {
 			real x[3], R[9];
 			if (mode == 1) {

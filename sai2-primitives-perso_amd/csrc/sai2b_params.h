@@ -58,6 +58,7 @@ struct DevTask {
 	// internal OTG (JointTask.h:38-42, MotionForceTask.h:67-74); limits per OTG DoF (JT: task dof;
 	// MFT: 3 linear then 3 angular)
 	int otg_on, otg_n;
+	int otg_out_is_desired;	 // full JointTask: the generator's output rows already have the goals' layout, no copy kept
 	double otg_vmax[N], otg_amax[N];
 	double otg_epoch;  // bumped when the limits change: every moving robot re-plans on its next tick
 	// device buffers of this task
