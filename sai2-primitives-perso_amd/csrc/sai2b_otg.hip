@@ -68,6 +68,15 @@ DI void load_body(const real* S, int n, bool cart, int B, int b, Gen& g) {
 	load7(S, OTG_OUT, n, B, b, g.np);
 	load7(S, OTG_OUT + MD, n, B, b, g.nv);
 	load7(S, OTG_OUT + 2 * MD, n, B, b, g.na);
+	if (ldflag(S, OTG_IN_SYNC, B, b) != 0) {  // see OTG_IN_SYNC: the rows just read are stale, the state is the output
+		UNROLL for (int d = 0; d < MD; d++) {
+			g.in.cp[d] = g.ci.cp[d] = g.np[d];
+			g.in.cv[d] = g.ci.cv[d] = g.nv[d];
+			g.in.ca[d] = g.ci.ca[d] = g.na[d];
+			g.ci.tp[d] = g.in.tp[d];
+			g.ci.tv[d] = g.in.tv[d];
+		}
+	}
 	g.time = ld(S, OTG_TIME, B, b);
 	g.traj.duration = ld(S, OTG_DURATION, B, b);
 	g.ci_init = ldflag(S, OTG_CI_INIT, B, b);
@@ -113,6 +122,7 @@ DI void store_state(real* S, int n, bool cart, int B, int b, const Gen& g) {
 	st(S, OTG_TARGET_SET, B, b, (double)g.target_set);
 	st(S, OTG_CI_INIT, B, b, (double)g.ci_init);
 	st(S, OTG_CI_EPOCH, B, b, g.ci_epoch);
+	st(S, OTG_IN_SYNC, B, b, 0.0);
 	if (cart) {
 		UNROLL for (int i = 0; i < 9; i++) st(S, OTG_CART + i, B, b, g.ref[i]);
 		UNROLL for (int i = 0; i < 9; i++) st(S, OTG_CART + 9 + i, B, b, g.goal_R[i]);
@@ -169,8 +179,9 @@ DI void load_goals(const DevTask& t, bool cart, int n, int B, int b, Goals& G) {
 //   PLAN    the goal changed (setGoal... will touch the input) or the input differs from the stored
 //           one (ruckig.hpp:194): the full update with the planner, done by otg_plan_kernel.
 enum { IDLE = 0, SAMPLE = 1, PLAN = 2 };
-DI int classify(const DevTask& t, bool cart, int n, int B, int b, Gen& g, Goals& G, bool goals_clean) {
+DI int classify(const DevTask& t, bool cart, int n, int B, int b, Gen& g, Goals& G, bool goals_clean, bool& in_sync) {
 	const real* S = t.otg_state;
+	in_sync = false;
 	// The host has not touched this task's goals (nor its OTG configuration) since the previous
 	// update: for a robot whose goal is reached setGoal...() is the same no-op as last time, so its
 	// flag alone decides (1 row instead of ~35)
@@ -187,6 +198,10 @@ DI int classify(const DevTask& t, bool cart, int n, int B, int b, Gen& g, Goals&
 	}
 	if (!unchanged) return PLAN;
 	if (g.goal_reached) return IDLE;
+	in_sync = ldflag(S, OTG_IN_SYNC, B, b) != 0;
+	g.ci_init = ldflag(S, OTG_CI_INIT, B, b);
+	g.ci_epoch = ld(S, OTG_CI_EPOCH, B, b);
+	if (in_sync) return (g.ci_epoch != t.otg_epoch || !g.ci_init) ? PLAN : SAMPLE;  // inputs equal by definition
 	load7(S, OTG_IN, n, B, b, g.in.cp);
 	load7(S, OTG_IN + MD, n, B, b, g.in.cv);
 	load7(S, OTG_IN + 2 * MD, n, B, b, g.in.ca);
@@ -195,8 +210,6 @@ DI int classify(const DevTask& t, bool cart, int n, int B, int b, Gen& g, Goals&
 	load7(S, OTG_CI + 2 * MD, n, B, b, g.ci.ca);
 	load7(S, OTG_CI + 3 * MD, n, B, b, g.ci.tp);
 	load7(S, OTG_CI + 4 * MD, n, B, b, g.ci.tv);
-	g.ci_init = ldflag(S, OTG_CI_INIT, B, b);
-	g.ci_epoch = ld(S, OTG_CI_EPOCH, B, b);
 	return otg::needs_plan(g, n, t.otg_epoch) ? PLAN : SAMPLE;
 }
 
@@ -220,40 +233,53 @@ DI void load_traj(const real* S, int n, bool cart, int B, int b, Gen& g) {
 	}
 }
 
-// SAMPLE: Ruckig::update without a new calculation, then the wrapper's bookkeeping
-DI void sample_lane(const DevTask& t, bool cart, int n, int B, int b, Gen& g) {
+// SAMPLE: Ruckig::update without a new calculation, then the wrapper's bookkeeping. `in_sync` on entry:
+// the input rows were not loaded (they equal the output, OTG_IN_SYNC).
+DI void sample_lane(const DevTask& t, bool cart, int n, int B, int b, Gen& g, bool in_sync) {
 	real* S = t.otg_state;
 	load_traj(S, n, cart, B, b, g);
 	g.result = otg::ruckig_sample(g, n, t.dt, otg::WORKING);
-	otg::Prev none;	 // the error branch cannot be taken without a calculation
-	if (cart)
-		otg::cart_finish(g, none);
-	else
-		otg::joints_finish(g, n, none);
-	store7(S, OTG_IN, n, B, b, g.in.cp);
-	store7(S, OTG_IN + MD, n, B, b, g.in.cv);
-	store7(S, OTG_IN + 2 * MD, n, B, b, g.in.ca);
-	store7(S, OTG_CI, n, B, b, g.ci.cp);
-	store7(S, OTG_CI + MD, n, B, b, g.ci.cv);
-	store7(S, OTG_CI + 2 * MD, n, B, b, g.ci.ca);
+	if (g.result == otg::WORKING) {
+		// both pass_to_input calls: input, Ruckig's stored input and output are one state again
+		if (!in_sync) st(S, OTG_IN_SYNC, B, b, 1.0);
+	} else {
+		// Finished: Ruckig's stored input follows the output, the wrapper's input stays where it was
+		// (OTG_joints.cpp:125-135): back to explicit rows
+		if (in_sync) {	// where it was = the previous output, still in memory
+			load7(S, OTG_OUT, n, B, b, g.in.cp);
+			load7(S, OTG_OUT + MD, n, B, b, g.in.cv);
+			load7(S, OTG_OUT + 2 * MD, n, B, b, g.in.ca);
+			UNROLL for (int d = 0; d < MD; d++) g.ci.tp[d] = g.in.tp[d], g.ci.tv[d] = g.in.tv[d];
+		}
+		otg::Prev none;	 // the error branch cannot be taken without a calculation
+		if (cart)
+			otg::cart_finish(g, none);
+		else
+			otg::joints_finish(g, n, none);
+		store7(S, OTG_IN, n, B, b, g.in.cp);
+		store7(S, OTG_IN + MD, n, B, b, g.in.cv);
+		store7(S, OTG_IN + 2 * MD, n, B, b, g.in.ca);
+		store7(S, OTG_IN + 3 * MD, n, B, b, g.in.tp);
+		store7(S, OTG_IN + 4 * MD, n, B, b, g.in.tv);
+		store7(S, OTG_CI, n, B, b, g.ci.cp);
+		store7(S, OTG_CI + MD, n, B, b, g.ci.cv);
+		store7(S, OTG_CI + 2 * MD, n, B, b, g.ci.ca);
+		store7(S, OTG_CI + 3 * MD, n, B, b, g.ci.tp);
+		store7(S, OTG_CI + 4 * MD, n, B, b, g.ci.tv);
+		st(S, OTG_IN_SYNC, B, b, 0.0);
+		st(S, OTG_GOAL_REACHED, B, b, (double)g.goal_reached);
+		st(S, OTG_TARGET_SET, B, b, (double)g.target_set);
+		if (cart && !g.goal_reached) {
+			UNROLL for (int i = 0; i < 9; i++) st(S, OTG_CART + i, B, b, g.ref[i]);
+			UNROLL for (int i = 0; i < 9; i++) st(S, OTG_CART + 9 + i, B, b, g.goal_R[i]);
+			UNROLL for (int i = 0; i < 3; i++) st(S, OTG_CART + 18 + i, B, b, g.goal_w[i]);
+		}
+	}
 	store7(S, OTG_OUT, n, B, b, g.np);
 	store7(S, OTG_OUT + MD, n, B, b, g.nv);
 	store7(S, OTG_OUT + 2 * MD, n, B, b, g.na);
 	st(S, OTG_TIME, B, b, g.time);
 	st(S, OTG_RESULT, B, b, (double)g.result);
-	if (g.result == otg::FINISHED) {  // goal reached, or re-targeted to stop (rare): the head changes too
-		st(S, OTG_GOAL_REACHED, B, b, (double)g.goal_reached);
-		if (!g.goal_reached) {
-			store7(S, OTG_IN + 3 * MD, n, B, b, g.in.tp);
-			store7(S, OTG_IN + 4 * MD, n, B, b, g.in.tv);
-			st(S, OTG_TARGET_SET, B, b, (double)g.target_set);
-			if (cart) {
-				UNROLL for (int i = 0; i < 9; i++) st(S, OTG_CART + i, B, b, g.ref[i]);
-				UNROLL for (int i = 0; i < 9; i++) st(S, OTG_CART + 9 + i, B, b, g.goal_R[i]);
-				UNROLL for (int i = 0; i < 3; i++) st(S, OTG_CART + 18 + i, B, b, g.goal_w[i]);
-			}
-		}
-	}
 	if (cart)
 		store_desired_cart(t.otg_desired, B, b, g);
 	else if (!t.otg_out_is_desired)
@@ -275,6 +301,10 @@ DI void plan_group(const DevTask& t, bool cart, int n, int B, int b) {
 	g.ci_cp = row(OTG_CI), g.ci_cv = row(OTG_CI + MD), g.ci_ca = row(OTG_CI + 2 * MD), g.ci_tp = row(OTG_CI + 3 * MD),
 	g.ci_tv = row(OTG_CI + 4 * MD);
 	g.np = row(OTG_OUT), g.nv = row(OTG_OUT + MD), g.na = row(OTG_OUT + 2 * MD);
+	if (ldflag(S, OTG_IN_SYNC, B, b) != 0) {  // see OTG_IN_SYNC
+		g.in_cp = g.ci_cp = g.np, g.in_cv = g.ci_cv = g.nv, g.in_ca = g.ci_ca = g.na;
+		g.ci_tp = g.in_tp, g.ci_tv = g.in_tv;
+	}
 	{
 		const int r = OTG_TRAJ + (active ? j : 0) * OTG_TRAJ_STRIDE;
 		g.f.brake_t = ld(S, r, B, b), g.f.brake_a = ld(S, r + 1, B, b), g.f.brake_p = ld(S, r + 2, B, b);
@@ -338,6 +368,7 @@ DI void plan_group(const DevTask& t, bool cart, int n, int B, int b) {
 		st(S, OTG_TARGET_SET, B, b, (double)g.target_set);
 		st(S, OTG_CI_INIT, B, b, (double)g.ci_init);
 		st(S, OTG_CI_EPOCH, B, b, g.ci_epoch);
+		st(S, OTG_IN_SYNC, B, b, 0.0);
 		if (cart) {
 			UNROLL for (int i = 0; i < 9; i++) st(S, OTG_CART + i, B, b, g.ref[i]), st(S, OTG_CART + 9 + i, B, b, g.goal_R[i]);
 			UNROLL for (int i = 0; i < 3; i++) st(S, OTG_CART + 18 + i, B, b, g.goal_w[i]);
@@ -377,8 +408,9 @@ __global__ __launch_bounds__(64) void otg_kernel(const DevParams* __restrict__ P
 		if (live) {
 			Gen g;
 			Goals G;
-			cls = classify(tk, cart, tk.otg_n, B, b, g, G, ((clean_mask >> t) & 1) != 0);
-			if (cls == SAMPLE) sample_lane(tk, cart, tk.otg_n, B, b, g);
+			bool in_sync;
+			cls = classify(tk, cart, tk.otg_n, B, b, g, G, ((clean_mask >> t) & 1) != 0, in_sync);
+			if (cls == SAMPLE) sample_lane(tk, cart, tk.otg_n, B, b, g, in_sync);
 		}
 		const unsigned long long mask = __ballot(cls == PLAN);
 		if (mask) {

@@ -89,10 +89,15 @@ constexpr int OTG_CI = 35;	  // Ruckig current_input: cp cv ca tp tv
 constexpr int OTG_OUT = 70;	  // _output: new position, velocity, acceleration
 constexpr int OTG_TIME = 91, OTG_DURATION = 92, OTG_GOAL_REACHED = 93, OTG_RESULT = 94, OTG_TARGET_SET = 95,
 			  OTG_CI_INIT = 96, OTG_CI_EPOCH = 97, OTG_CONSTRUCTED = 98;
+// OTG_IN_SYNC != 0: the wrapper's input state and Ruckig's stored one both equal the output (the normal
+// case after a step along the trajectory: pass_to_input twice, OTG_joints.cpp:137, ruckig.hpp:209) and
+// the stored targets are equal; their rows (IN c*, CI c*, CI t*) are then not kept up to date
+constexpr int OTG_IN_SYNC = 190 + 21;  // = OTG_CART + 21
 constexpr int OTG_TRAJ = 99;  // per DoF: brake t a p v, p0 v0, t0 t1 t2 t6, a0 a2 a6
 constexpr int OTG_TRAJ_STRIDE = 13;
 constexpr int OTG_CART = OTG_TRAJ + 7 * OTG_TRAJ_STRIDE;  // reference frame 9, goal orientation 9, goal angular velocity 3
-constexpr int OTG_ROWS = OTG_CART + 21;
+constexpr int OTG_ROWS = OTG_CART + 22;
+static_assert(OTG_IN_SYNC == OTG_CART + 21, "row layout");
 constexpr int MFT_STATE_ROWS = 33;
 constexpr int MFT_ISTATE_ROWS = 12;
 constexpr int POPC_RING = 1024;	 // capacity of the PO window ring (the reference queue is unbounded)
