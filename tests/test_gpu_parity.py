@@ -534,3 +534,31 @@ def test_task_observers_between_ticks():
     assert np.abs(mft.getCurrentPosition() - sg["pos"]).max() < 1e-12
     assert np.array_equal(jt.getCurrentPosition(), inp["q"]) and np.array_equal(mft.getGoalPosition(), inp["mft0"]["pos"])
     del ctl
+
+
+def test_new_entry_points_reject_bad_arguments():
+    """argument checks of the observers / simulation / integrator entry points (no state is touched)"""
+    B = 64
+    inp = pkg.workloads.make_inputs(3, B=B, seed=3)
+    g = pkg.Controller(pkg.panda_model(), pkg.task_configs(inp["tasks"]), B)
+    ol.load_inputs(g, inp)
+    tau0 = g.tick()
+    with pytest.raises(ValueError, match="dt must be > 0"):
+        g.sim_step(None, dt=0.0)
+    with pytest.raises(ValueError, match="substeps"):
+        g.sim_step(None, dt=0.001, substeps=0)
+    with pytest.raises(ValueError, match="not a JointTask"):
+        g.get_jt_desired(0)
+    with pytest.raises(ValueError, match="not a MotionForceTask"):
+        g.get_mft_desired(1)
+    with pytest.raises(ValueError, match="not a MotionForceTask"):
+        g.get_mft_status(1)
+    with pytest.raises(ValueError, match="not a JointTask"):
+        g.get_jt_goals(0)
+    with pytest.raises(ValueError, match="bad arguments"):
+        g.reset_integrators(7)
+    with pytest.raises(ValueError, match="bad arguments"):
+        g.get_otg_status(-1)
+    with pytest.raises(ValueError):
+        g.sim_step(np.zeros((7, B + 1)))
+    assert np.array_equal(g.tick(), tau0)  # nothing moved
