@@ -324,8 +324,13 @@ int sai2b_get_model(sai2b_ctx* ctx, int task, double* M, double* J, double* pos,
 
 /* Bench bookkeeping: run `steps` fused ticks with HIP events around each kernel launch of the tick (on
  * the ctx stream) and return the average duration per launch in ms: the first kernel of the tick and,
- * when the hierarchy takes the SVD-free path, the flag-gated generic kernel behind it (else 0). */
+ * when the hierarchy takes the SVD-free path, the generic kernel over its work list behind it (else 0). */
 int sai2b_profile_tick(sai2b_ctx* ctx, int steps, double* first_kernel_ms, double* second_kernel_ms);
+
+/* How many robots of the last tick the SVD-free kernel handed to the generic (Jacobi-SVD) kernel: those
+ * inside or leaving a singularity-blending region (SingularityHandler.cpp:66-160). 0 for hierarchies
+ * that run the generic kernel for every robot. Waits for the ctx stream. */
+int sai2b_get_fallback_count(sai2b_ctx* ctx, int* robots);
 
 /* number of kernel launches and robots processed since creation (bench bookkeeping) */
 int sai2b_counters(const sai2b_ctx* ctx, long long* launches, long long* ticks);

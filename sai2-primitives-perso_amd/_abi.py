@@ -208,6 +208,7 @@ EXPORTS = [
     "sai2b_get_otg_status",
     "sai2b_get_model",
     "sai2b_profile_tick",
+    "sai2b_get_fallback_count",
     "sai2b_counters",
 ]
 
@@ -284,6 +285,7 @@ def load_library():
     lib.sai2b_get_otg_status.argtypes = [vp, _i, vp, vp]
     lib.sai2b_get_model.argtypes = [vp, _i, vp, vp, vp, vp]
     lib.sai2b_profile_tick.argtypes = [vp, _i, P(_d), P(_d)]
+    lib.sai2b_get_fallback_count.argtypes = [vp, P(_i)]
     lib.sai2b_counters.argtypes = [vp, P(C.c_longlong), P(C.c_longlong)]
     _lib = lib
     return lib

@@ -243,6 +243,12 @@ class Controller:
         self._rc(self.lib.sai2b_profile_tick(self.h, int(steps), C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def fallback_count(self):
+        """robots of the last tick that ran the generic (Jacobi-SVD) kernel behind the SVD-free one"""
+        n = C.c_int()
+        self._rc(self.lib.sai2b_get_fallback_count(self.h, C.byref(n)))
+        return n.value
+
     def counters(self):
         a, b = C.c_longlong(), C.c_longlong()
         self.lib.sai2b_counters(self.h, C.byref(a), C.byref(b))

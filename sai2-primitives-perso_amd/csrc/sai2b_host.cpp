@@ -31,7 +31,9 @@ struct sai2b_ctx {
 	bool params_dirty = true;
 	bool baked_model = false;  // the ctx model is bit-equal to the compile-time Panda constants
 	bool no_fast_path = false;	// SAI2B_NO_FAST_PATH=1 in the environment: always run the generic kernel
-	int* wave_flags = nullptr;	// per-wavefront "needs the generic path" flags of the fast kernel
+	int* fb_counts = nullptr;	// [2] robots the SVD-free kernel handed to the generic one (alternating by fb_parity)
+	int* fb_list = nullptr;		// [B] their indices
+	int fb_parity = 0;			// counter set of the last SVD-free launch
 	int* otg_counts = nullptr;	// [2][MAX_TASKS] work-list counters of the trajectory planner (sai2b_otg.hip)
 	int* otg_list = nullptr;	// [MAX_TASKS][B] robots that need the planner this tick
 	int otg_parity = 0;
@@ -546,7 +548,8 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	if ((rc = dev_alloc(ctx, &ctx->dq, N * Bs))) return rc;
 	if ((rc = dev_alloc(ctx, &ctx->tau, N * Bs))) return rc;
 	hp.q = ctx->q, hp.dq = ctx->dq, hp.tau = ctx->tau;
-	if ((rc = dev_alloc(ctx, &ctx->wave_flags, (Bs + 63) / 64))) return rc;
+	if ((rc = dev_alloc(ctx, &ctx->fb_counts, 2))) return rc;
+	if ((rc = dev_alloc(ctx, &ctx->fb_list, Bs))) return rc;
 	if ((rc = dev_alloc(ctx, &ctx->otg_counts, 2 * SAI2B_MAX_TASKS))) return rc;
 	if ((rc = dev_alloc(ctx, &ctx->otg_list, SAI2B_MAX_TASKS * Bs))) return rc;
 	for (int t = 0; t < n_tasks; t++) {
@@ -787,7 +790,9 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 		ctx->otg_parity ^= 1;
 		ctx->launches += 2;
 	}
-	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, ctx->baked_model ? 1 : 0, commit_sh, with_comp, do_torque, ctx->wave_flags, ctx->stream))
+	const bool fast_launch = fast != 0 && !ctx->introspection && do_torque && commit_sh;
+	if (fast_launch) ctx->fb_parity ^= 1;
+	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, ctx->baked_model ? 1 : 0, commit_sh, with_comp, do_torque, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
 	ctx->launches++;
 	return SAI2B_OK;
@@ -1075,7 +1080,7 @@ extern "C" int sai2b_get_model(sai2b_ctx* ctx, int task, double* M, double* J, d
 // Bench bookkeeping: run `steps` fused ticks with HIP events around EACH kernel launch of the tick on
 // the ctx stream and return the average duration per launch in milliseconds: first kernel of the tick
 // (the SVD-free kernel when the hierarchy is eligible, else the generic kernel) and, when there is
-// one, the flag-gated generic kernel behind it (0 otherwise).
+// one, the generic kernel over its work list behind it (0 otherwise).
 extern "C" int sai2b_profile_tick(sai2b_ctx* ctx, int steps, double* first_ms, double* second_ms) {
 	if (!ctx || steps < 1) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_profile_tick: bad arguments");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1087,10 +1092,11 @@ extern "C" int sai2b_profile_tick(sai2b_ctx* ctx, int steps, double* first_ms, d
 	for (auto& e : ev) HIP_TRY(ctx, hipEventCreate(&e));
 	for (int s = 0; s < steps; s++) {
 		HIP_TRY(ctx, hipEventRecord(ev[3 * s], ctx->stream));
-		if (sai2b_launch_tick_part(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, ctx->baked_model ? 1 : 0, 0, ctx->wave_flags, ctx->stream))
+		if (two) ctx->fb_parity ^= 1;
+		if (sai2b_launch_tick_part(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, ctx->baked_model ? 1 : 0, 0, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, ctx->stream))
 			return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
 		HIP_TRY(ctx, hipEventRecord(ev[3 * s + 1], ctx->stream));
-		if (two && sai2b_launch_tick_part(ctx->d_params, ctx->B, 0, fast, ctx->baked_model ? 1 : 0, 1, ctx->wave_flags, ctx->stream))
+		if (two && sai2b_launch_tick_part(ctx->d_params, ctx->B, 0, fast, ctx->baked_model ? 1 : 0, 1, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, ctx->stream))
 			return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
 		HIP_TRY(ctx, hipEventRecord(ev[3 * s + 2], ctx->stream));
 	}
@@ -1108,6 +1114,14 @@ extern "C" int sai2b_profile_tick(sai2b_ctx* ctx, int steps, double* first_ms, d
 	ctx->ticks += (long long)steps * ctx->B;
 	if (first_ms) *first_ms = a / steps;
 	if (second_ms) *second_ms = two ? b / steps : 0.0;
+	return SAI2B_OK;
+}
+
+extern "C" int sai2b_get_fallback_count(sai2b_ctx* ctx, int* robots) {
+	if (!ctx || !robots) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_get_fallback_count: bad arguments");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, hipMemcpyAsync(robots, ctx->fb_counts + ctx->fb_parity, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return SAI2B_OK;
 }
 

@@ -14,14 +14,19 @@
 namespace sai2b {
 
 // Generic tick: Jacobi-SVD based, any hierarchy (the reference's control flow, projector form).
-// wave_flags != NULL: only wavefronts whose flag is set run (the fallback pass behind tick_fast_kernel).
+// fb_count != NULL: the fallback pass behind tick_fast_kernel — lane i of the grid takes robot
+// fb_list[i] for i < *fb_count (the robots the SVD-free kernel declined, compacted), the rest exits.
 template <bool DEBUG>
 __global__ __launch_bounds__(64) void tick_kernel(const DevParams* __restrict__ Pp, int commit_sh, int with_comp,
-													 int do_torque, const int* __restrict__ wave_flags) {
-	if (wave_flags && ((const gint*)wave_flags)[blockIdx.x] == 0) return;
+													 int do_torque, const int* __restrict__ fb_count,
+													 const int* __restrict__ fb_list) {
 	const DevParams& P = *Pp;
 	const int B = P.B;
-	const int b = blockIdx.x * 64 + threadIdx.x;
+	int b = blockIdx.x * 64 + threadIdx.x;
+	if (fb_count) {
+		if (b >= *(const gint*)fb_count) return;
+		b = ((const gint*)fb_list)[b];
+	}
 	if (b >= B) return;
 	RobotCtx rc;
 	UNROLL for (int i = 0; i < N; i++) {
@@ -82,18 +87,22 @@ __global__ __launch_bounds__(64) void tick_kernel(const DevParams* __restrict__ 
 }
 
 // FAST = 1: hierarchy [full MFT]; FAST = 2: [full MFT, full JT] — the SVD-free path of
-// sai2b_fast.hpp. A wavefront runs it only when all of its robots are certified non-singular (and
-// none is leaving a singular region); otherwise it touches no state, raises its flag in wave_flags
-// and the flag-gated generic kernel launched right behind handles that wavefront.
+// sai2b_fast.hpp. A robot takes it only when it is certified non-singular (and is not leaving a
+// singular region); otherwise its lane touches no state and appends the robot to the work list of
+// the generic kernel launched right behind (one atomic per wavefront that has such robots).
+// fb_counts: two counters alternating between ticks (`parity`): this launch fills [parity] and clears
+// [1 - parity] for the next one (the generic pass that read it finished before this kernel started).
 // BAKED selects where the robot constants come from: false = the ctx's parameter block (any robot),
 // true = the compile-time Panda literals of sai2b_baked_panda.h (chosen by the host only when the ctx
 // model is bit-equal to them): no scalar loads from the parameter block for the model phase.
 template <int FAST, bool BAKED>
 __global__ __launch_bounds__(64) void tick_fast_kernel(const DevParams* __restrict__ Pp, int with_comp,
-														  int* __restrict__ wave_flags) {
+														  int* __restrict__ fb_counts, int* __restrict__ fb_list,
+														  int parity) {
 	const DevParams& P = *Pp;
 	const int B = P.B;
 	const int b = blockIdx.x * 64 + threadIdx.x;
+	if (blockIdx.x == 0 && threadIdx.x == 0) ((gint*)fb_counts)[1 - parity] = 0;
 	if (b >= B) return;
 	RobotCtx rc;
 	UNROLL for (int i = 0; i < N; i++) {
@@ -139,9 +148,17 @@ __global__ __launch_bounds__(64) void tick_fast_kernel(const DevParams* __restri
 	}
 	SAI2B_PHASE();
 	const bool ok = certify_nonsingular(J, t0.s_abs_tol, t0.s_max);
-	const bool all_ok = __all(ok && clean);
-	if (threadIdx.x == 0) ((gint*)wave_flags)[blockIdx.x] = all_ok ? 0 : 1;
-	if (!all_ok) return;
+	const bool mine = ok && clean;
+	const unsigned long long declined = __ballot(!mine);
+	if (declined) {
+		int base = 0;
+		if (threadIdx.x == 0) base = atomicAdd(&fb_counts[parity], __popcll(declined));  // lane 0 is always in range
+		base = __shfl(base, 0);
+		if (!mine) {
+			((gint*)fb_list)[base + __popcll(declined & ((1ull << threadIdx.x) - 1ull))] = b;
+			return;
+		}
+	}
 	// committed to the fast path: integrators can go out now
 	mft_store_integrators(t0, B, b, in0);
 	if (FAST == 2) {
@@ -199,44 +216,45 @@ __global__ __launch_bounds__(64) void reinit_kernel(const DevParams* __restrict_
 }  // namespace sai2b
 
 static void launch_fast(int fast, int baked, dim3 grid, dim3 block, hipStream_t stream, const sai2b::DevParams* d_params,
-						int with_comp, int* wave_flags) {
+						int with_comp, int* fb_counts, int* fb_list, int parity) {
 	if (fast == 2 && baked)
-		hipLaunchKernelGGL((sai2b::tick_fast_kernel<2, true>), grid, block, 0, stream, d_params, with_comp, wave_flags);
+		hipLaunchKernelGGL((sai2b::tick_fast_kernel<2, true>), grid, block, 0, stream, d_params, with_comp, fb_counts, fb_list, parity);
 	else if (fast == 2)
-		hipLaunchKernelGGL((sai2b::tick_fast_kernel<2, false>), grid, block, 0, stream, d_params, with_comp, wave_flags);
+		hipLaunchKernelGGL((sai2b::tick_fast_kernel<2, false>), grid, block, 0, stream, d_params, with_comp, fb_counts, fb_list, parity);
 	else if (baked)
-		hipLaunchKernelGGL((sai2b::tick_fast_kernel<1, true>), grid, block, 0, stream, d_params, with_comp, wave_flags);
+		hipLaunchKernelGGL((sai2b::tick_fast_kernel<1, true>), grid, block, 0, stream, d_params, with_comp, fb_counts, fb_list, parity);
 	else
-		hipLaunchKernelGGL((sai2b::tick_fast_kernel<1, false>), grid, block, 0, stream, d_params, with_comp, wave_flags);
+		hipLaunchKernelGGL((sai2b::tick_fast_kernel<1, false>), grid, block, 0, stream, d_params, with_comp, fb_counts, fb_list, parity);
 }
 
 extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int commit_sh,
-								 int with_comp, int do_torque, int* wave_flags, hipStream_t stream) {
+								 int with_comp, int do_torque, int* fb_counts, int* fb_list, int parity, hipStream_t stream) {
 	const dim3 grid((B + 63) / 64), block(64);
 	// the fast path produces torques only: introspection and model-only passes use the generic kernel
 	if (debug) {
-		hipLaunchKernelGGL((sai2b::tick_kernel<true>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, nullptr);
+		hipLaunchKernelGGL((sai2b::tick_kernel<true>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, nullptr, nullptr);
 	} else if (fast != 0 && do_torque && commit_sh) {
-		launch_fast(fast, baked, grid, block, stream, d_params, with_comp, wave_flags);
-		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, wave_flags);
+		launch_fast(fast, baked, grid, block, stream, d_params, with_comp, fb_counts, fb_list, parity);
+		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque,
+						   (const int*)(fb_counts + parity), (const int*)fb_list);
 	} else {
-		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, nullptr);
+		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, nullptr, nullptr);
 	}
 	return (int)hipGetLastError();
 }
 
 extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int part,
-									  int* wave_flags,
-									  hipStream_t stream) {
+									  int* fb_counts, int* fb_list, int parity, hipStream_t stream) {
 	const dim3 grid((B + 63) / 64), block(64);
 	if (debug)
-		hipLaunchKernelGGL((sai2b::tick_kernel<true>), grid, block, 0, stream, d_params, 1, 1, 1, nullptr);
+		hipLaunchKernelGGL((sai2b::tick_kernel<true>), grid, block, 0, stream, d_params, 1, 1, 1, nullptr, nullptr);
 	else if (fast == 0)
-		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, 1, 1, 1, nullptr);
+		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, 1, 1, 1, nullptr, nullptr);
 	else if (part == 1)
-		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, 1, 1, 1, wave_flags);
+		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, 1, 1, 1, (const int*)(fb_counts + parity),
+						   (const int*)fb_list);
 	else
-		launch_fast(fast, baked, grid, block, stream, d_params, 1, wave_flags);
+		launch_fast(fast, baked, grid, block, stream, d_params, 1, fb_counts, fb_list, parity);
 	return (int)hipGetLastError();
 }
 

@@ -5,13 +5,13 @@
 #include "sai2b_params.h"
 
 extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int commit_sh,
-								 int with_comp, int do_torque, int* wave_flags, hipStream_t stream);
+								 int with_comp, int do_torque, int* fb_counts, int* fb_list, int parity, hipStream_t stream);
 extern "C" int sai2b_launch_reinit(const sai2b::DevParams* d_params, int B, hipStream_t stream);
 // one kernel of a (fast) tick on its own, for per-kernel timing: part 0 = first kernel, part 1 = the
-// flag-gated generic kernel behind the SVD-free one
+// generic kernel over the work list of the SVD-free one. fb_counts: 2 ints, zero before the first
+// launch; fb_list: B ints; parity alternates 0/1 between consecutive launches of the SVD-free kernel
 extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int part,
-									  int* wave_flags,
-									  hipStream_t stream);
+									  int* fb_counts, int* fb_list, int parity, hipStream_t stream);
 // internal OTG (sai2b_otg.hip): one update of every enabled generator; (re)initialisation (modes in the kernel's comment)
 extern "C" int sai2b_launch_otg(const sai2b::DevParams* d_params, int B, int* counts, int* list, int parity, int clean_mask,
 								hipStream_t stream);

@@ -43,6 +43,7 @@ for otg in (False, True):
     run(STEPS)
     dt = (time.perf_counter() - t0) / STEPS
     q, dq = c.get_state()
+    print(f"  robots in the generic kernel at the last period: {c.fallback_count()} of {B}")
     print(f"closed loop, OTG {'on ' if otg else 'off'}: {dt * 1e6:7.1f} us per control period  {B / dt / 1e9:.2f} G robot-periods/s  "
           f"(simulated time / wall time per robot = {0.001 / dt:.1f}x, max|dq| = {np.abs(dq).max():.3f})")
     c.close()
