@@ -1156,6 +1156,7 @@ DI void jt_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B,
 			PR[i * N + k] = PR[k * N + i] = a;
 		}
 	}
+	if (t.otg_gated && !do_torque) st(t.otg_state, OTG_ACTIVE, B, b, zero_range ? 0.0 : 1.0);  // read by otg_kernel
 	real tau[N];
 	UNROLL for (int i = 0; i < N; i++) tau[i] = 0;
 	real Ntask[N * N];

@@ -647,7 +647,7 @@ extern "C" int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_ta
 	d.dbg_tau = keep.dbg_tau, d.dbg_N = keep.dbg_N, d.dbg_sigma = keep.dbg_sigma, d.dbg_J = keep.dbg_J, d.dbg_pose = keep.dbg_pose;
 	d.dbg_F = keep.dbg_F;
 	d.otg_desired = keep.otg_desired, d.otg_state = keep.otg_state, d.otg_epoch = keep.otg_epoch;
-	d.otg_out_is_desired = keep.otg_out_is_desired;
+	d.otg_out_is_desired = keep.otg_out_is_desired, d.otg_gated = keep.otg_gated;
 	d.law_goals = d.otg_on ? (d.otg_out_is_desired ? d.otg_state + (size_t)sai2b::OTG_OUT * ctx->B : d.otg_desired) : d.goals;
 	ctx->params_dirty = true;
 	ctx->goals_dirty |= 1u << task;
@@ -778,13 +778,46 @@ static bool any_otg(const sai2b_ctx* ctx) {
 	return false;
 }
 
+// Which JointTasks need their generator gated per robot and tick: one whose range can come out empty
+// (JointTask.cpp:233-239,302-306: the task then returns before setGoal / update of its OTG). Never the
+// case for the first task (range of S) nor for an invertible selection behind fewer than 7 task DoF
+// (S N_prec has the rank of N_prec >= 1, and a non-zero projector has a singular value >= 1).
+static unsigned refresh_otg_gating(sai2b_ctx* ctx) {
+	unsigned mask = 0;
+	int dof_above = 0;
+	for (int t = 0; t < ctx->h_params.n_tasks; t++) {
+		DevTask& d = ctx->h_params.task[t];
+		int gated = 0;
+		if (d.type == SAI2B_JOINT_TASK) {
+			gated = (d.otg_on && t > 0 && !(d.k0 == N && dof_above < N)) ? 1 : 0;
+			dof_above += d.k0;
+		} else {
+			dof_above += d.rank;
+		}
+		if (d.otg_gated != gated) {
+			d.otg_gated = gated;
+			ctx->params_dirty = true;
+		}
+		if (gated) mask |= 1u << t;
+	}
+	return mask;
+}
+
 static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torque) {
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const unsigned gated = refresh_otg_gating(ctx);
 	int rc = upload_params(ctx);
 	if (rc) return rc;
 	const int fast = fast_kind(ctx);
+	if (do_torque && gated) {
+		// which robots' gated tasks are active this tick: the task models of the current state, nothing committed
+		if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, 0, 0, /*commit_sh=*/0, with_comp, /*do_torque=*/0, nullptr, nullptr, 0, ctx->stream))
+			return set_error(ctx, SAI2B_RUNTIME_ERROR, "task-range pass launch failed");
+		ctx->launches++;
+	}
 	if (do_torque && any_otg(ctx)) {  // the generators advance once per torque computation, before the law
-		const int clean_mask = ctx->goals_exposed ? 0 : (int)(~ctx->goals_dirty & ((1u << SAI2B_MAX_TASKS) - 1u));
+		// (a gated task keeps reading its goals: a robot skipped while they changed must see them later)
+		const int clean_mask = ctx->goals_exposed ? 0 : (int)(~ctx->goals_dirty & ~gated & ((1u << SAI2B_MAX_TASKS) - 1u));
 		ctx->goals_dirty = 0;
 		if (sai2b_launch_otg(ctx->d_params, ctx->B, ctx->otg_counts, ctx->otg_list, ctx->otg_parity, clean_mask, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG launch failed");
 		ctx->otg_parity ^= 1;

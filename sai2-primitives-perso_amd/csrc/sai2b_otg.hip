@@ -405,7 +405,8 @@ __global__ __launch_bounds__(64) void otg_kernel(const DevParams* __restrict__ P
 		if (!tk.otg_on) continue;
 		const bool cart = tk.type == SAI2B_MOTION_FORCE_TASK;
 		int cls = IDLE;
-		if (live) {
+		// a JointTask with an empty range returns before it touches its generator (JointTask.cpp:302-306)
+		if (live && !(tk.otg_gated && ld(tk.otg_state, OTG_ACTIVE, B, b) == 0.0)) {
 			Gen g;
 			Goals G;
 			bool in_sync;

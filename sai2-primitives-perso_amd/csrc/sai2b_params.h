@@ -59,6 +59,10 @@ struct DevTask {
 	// MFT: 3 linear then 3 angular)
 	int otg_on, otg_n;
 	int otg_out_is_desired;	 // full JointTask: the generator's output rows already have the goals' layout, no copy kept
+	// JointTask whose range can be empty for some robots and ticks (JointTask.cpp:302-306 returns before
+	// the generator is touched): a model-only pass ahead of otg_kernel writes OTG_ACTIVE per robot and
+	// the generator of an inactive robot is left alone for that tick
+	int otg_gated;
 	double otg_vmax[N], otg_amax[N];
 	double otg_epoch;  // bumped when the limits change: every moving robot re-plans on its next tick
 	// device buffers of this task
@@ -96,7 +100,8 @@ constexpr int OTG_IN_SYNC = 190 + 21;  // = OTG_CART + 21
 constexpr int OTG_TRAJ = 99;  // per DoF: brake t a p v, p0 v0, t0 t1 t2 t6, a0 a2 a6
 constexpr int OTG_TRAJ_STRIDE = 13;
 constexpr int OTG_CART = OTG_TRAJ + 7 * OTG_TRAJ_STRIDE;  // reference frame 9, goal orientation 9, goal angular velocity 3
-constexpr int OTG_ROWS = OTG_CART + 22;
+constexpr int OTG_ACTIVE = OTG_CART + 22;  // gated JointTask only: 1 = the task has a non-empty range this tick
+constexpr int OTG_ROWS = OTG_CART + 23;
 static_assert(OTG_IN_SYNC == OTG_CART + 21, "row layout");
 constexpr int MFT_STATE_ROWS = 33;
 constexpr int MFT_ISTATE_ROWS = 12;

@@ -127,7 +127,7 @@ def test_gpu_otg_generic_hierarchy_partial_joint_task():
     for c in (o, g):
         c.set_state(inp2["q"], inp2["dq"])
         c.reinitialize()
-    g2 = o.get_jt_desired(1)[0] + rng.normal(0, 0.2, (2, B))
+    g2 = o.get_jt_desired(1)[0] + rng.normal(0, 0.2, (1, B))
     g7 = o.get_jt_desired(2)[0] + rng.normal(0, 0.2, (7, B))
     d = o.get_mft_desired(0)
     gp = d[0] + rng.uniform(-0.05, 0.05, (3, B))
@@ -331,3 +331,72 @@ def test_gpu_otg_reinitialize_mid_motion_ragged_batch():
             assert np.abs(a - b_).max() < 1e-12, tick
     for a, b_ in zip(o.get_otg_status(1) + o2.get_otg_status(1), g.get_otg_status(1) + g2.get_otg_status(1)):
         assert np.array_equal(a, b_)
+
+
+def test_gpu_otg_of_task_with_empty_range_waits_like_the_reference():
+    """[MFT(6), JT(1 joint), JT(7)]: on a regular robot the last task has no degree of freedom left, and the
+    reference then returns before it touches the task's generator (JointTask.cpp:302-306), so the
+    generator waits — time, state and pending goal changes — until the task has a range again (here: when
+    the robot is moved into the 6-DOF task's singular region, whose handling strategy is off so that the
+    lost direction is passed down, and back). The GPU decides that per robot and tick with a model-only
+    pass ahead of the generator kernel (DevTask::otg_gated)."""
+    B = 96
+    inp = pkg.workloads.make_inputs(3, B=B, seed=12)
+    sel = np.zeros((1, N))
+    sel[0, 2] = 1
+    to = [ol.motion_force_task("m", internal_otg=True), ol.joint_task("j1", sel, internal_otg=True),
+          ol.joint_task("j7", internal_otg=True)]
+    tg = [pkg.motion_force_task_config("m", internal_otg=True), pkg.joint_task_config("j1", sel, internal_otg=True),
+          pkg.joint_task_config("j7", internal_otg=True)]
+    to[0].enforce_handling_strategy = tg[0].enforce_handling_strategy = 0
+    o = ol.Oracle(ol.panda_model(), to, B, threads=8)
+    g = pkg.Controller(pkg.panda_model(), tg, B, introspection=True)
+    q_reg = inp["q"].copy()
+    q_sing = q_reg.copy()
+    q_sing[3, : B // 2] = -0.0715  # elbow nearly extended: the 6-DOF task loses a direction for half the batch
+    rng = np.random.default_rng(5)
+    for c in (o, g):
+        c.set_state(q_reg, 0.1 * inp["dq"])
+        c.reinitialize()
+    g7 = o.get_jt_desired(2)[0] + rng.normal(0, 0.3, (N, B))
+    g2 = o.get_jt_desired(1)[0] + rng.normal(0, 0.2, (1, B))
+    waiting = moving = 0
+    ever_active = np.zeros(B, dtype=bool)
+    for tick in range(90):
+        if tick == 0:
+            for c in (o, g):
+                c.set_jt_goals(1, g2, None, None)
+                c.set_jt_goals(2, g7, None, None)
+        if tick == 10:  # goal change while the task is waiting on every robot
+            g7 = g7 + rng.normal(0, 0.2, (N, B))
+            for c in (o, g):
+                c.set_jt_goals(2, g7, None, None)
+        if tick in (20, 50):  # half the batch into the singular pose / back out of it
+            for c in (o, g):
+                c.set_state(q_sing if tick == 20 else q_reg, 0.1 * inp["dq"])
+        if tick == 35:  # and a goal change while it is moving for half of the robots
+            g7 = g7 + rng.normal(0, 0.2, (N, B))
+            for c in (o, g):
+                c.set_jt_goals(2, g7, None, None)
+        tau_o, tau_g = o.tick(), g.tick()
+        _, _, ro = o.get_mft_singularity(0)
+        e = _err(tau_g, tau_o)
+        assert e[ro == 6].max() < 10 * TOL, (tick, e[ro == 6].max())
+        assert e.max() < 1e-6, (tick, e.max())
+        for t in (1, 2):
+            for a, b_ in zip(o.get_jt_desired(t), g.get_jt_desired(t)):
+                assert np.abs(a - b_).max() < 1e-12, (tick, t)
+            for a, b_ in zip(o.get_otg_status(t), g.get_otg_status(t)):
+                assert np.array_equal(a, b_), (tick, t)
+        active = np.abs(o.get_task_torques(2)).max(axis=0) > 0
+        ever_active |= active
+        if 20 <= tick < 50:
+            moving += int(active[: B // 2].sum())
+        else:
+            waiting += int((~active).sum())
+    # the scenario did exercise both phases (a robot or two have the last task active in the regular pose too:
+    # there the one-joint task is the one with the empty range)
+    assert waiting > 0.95 * 60 * B and moving > 0.95 * 30 * (B // 2), (waiting, moving)
+    # the generator of a robot that waited all along never advanced: still at the state of reinitialize()
+    des_q = g.get_jt_desired(2)[0]
+    assert (~ever_active).sum() > B // 3 and np.abs(des_q[:, ~ever_active] - q_reg[:, ~ever_active]).max() < 1e-12
