@@ -34,6 +34,12 @@ struct sai2b_ctx {
 	int* fb_counts = nullptr;	// [2] robots the SVD-free kernel handed to the generic one (alternating by fb_parity)
 	int* fb_list = nullptr;		// [B] their indices
 	int fb_parity = 0;			// counter set of the last SVD-free launch
+	// The tasks' _current_position / _current_orientation are those of the last torque computation (or
+	// re-initialisation), and enabling an OTG starts its generator there (JointTask.cpp:374-376). While
+	// the state buffer still holds that state nothing is kept; the first write to it afterwards
+	// (set_state, sim_step) saves q here first.
+	double* q_pose = nullptr;	// [7][B]
+	bool q_is_pose = true;
 	int* otg_counts = nullptr;	// [2][MAX_TASKS] work-list counters of the trajectory planner (sai2b_otg.hip)
 	int* otg_list = nullptr;	// [MAX_TASKS][B] robots that need the planner this tick
 	int otg_parity = 0;
@@ -548,6 +554,7 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	if ((rc = dev_alloc(ctx, &ctx->dq, N * Bs))) return rc;
 	if ((rc = dev_alloc(ctx, &ctx->tau, N * Bs))) return rc;
 	hp.q = ctx->q, hp.dq = ctx->dq, hp.tau = ctx->tau;
+	if ((rc = dev_alloc(ctx, &ctx->q_pose, (size_t)N * Bs))) return rc;
 	if ((rc = dev_alloc(ctx, &ctx->fb_counts, 2))) return rc;
 	if ((rc = dev_alloc(ctx, &ctx->fb_list, Bs))) return rc;
 	if ((rc = dev_alloc(ctx, &ctx->otg_counts, 2 * SAI2B_MAX_TASKS))) return rc;
@@ -579,7 +586,7 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	if ((rc = upload_params(ctx))) return rc;
 	// the reference constructs tasks from the model's current state (q = 0 until set_state)
 	if (sai2b_launch_reinit(ctx->d_params, ctx->B, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "reinit launch failed");
-	if (sai2b_launch_otg_reinit(ctx->d_params, ctx->B, -1, 0, ctx->stream))
+	if (sai2b_launch_otg_reinit(ctx->d_params, ctx->B, -1, 0, ctx->q, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG reinit launch failed");
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return SAI2B_OK;
@@ -661,7 +668,7 @@ extern "C" int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_ta
 		if (limits_changed) d.otg_epoch += 1.0;
 		int rc3 = upload_params(ctx);
 		if (rc3) return rc3;
-		if (sai2b_launch_otg_reinit(ctx->d_params, ctx->B, task, keep.otg_on ? 2 : 1, ctx->stream))
+		if (sai2b_launch_otg_reinit(ctx->d_params, ctx->B, task, keep.otg_on ? 2 : 1, ctx->q_is_pose ? ctx->q : ctx->q_pose, ctx->stream))
 			return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG enable launch failed");
 		ctx->launches++;
 	}
@@ -683,10 +690,19 @@ static int copy_rows(sai2b_ctx* ctx, double* dst, const double* src, size_t rows
 	return SAI2B_OK;
 }
 
+// called before the state buffers are overwritten
+static int keep_pose(sai2b_ctx* ctx) {
+	if (!ctx->q_is_pose) return SAI2B_OK;
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->q_pose, ctx->q, sizeof(double) * N * (size_t)ctx->B, hipMemcpyDeviceToDevice, ctx->stream));
+	ctx->q_is_pose = false;
+	return SAI2B_OK;
+}
+
 extern "C" int sai2b_set_state(sai2b_ctx* ctx, const double* q, const double* dq, int on_device) {
 	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	int rc;
+	if (q && (rc = keep_pose(ctx))) return rc;
 	if ((rc = copy_rows(ctx, ctx->q, q, N, on_device))) return rc;
 	if ((rc = copy_rows(ctx, ctx->dq, dq, N, on_device))) return rc;
 	ctx->models_fresh = false;
@@ -753,11 +769,12 @@ extern "C" int sai2b_reinitialize(sai2b_ctx* ctx) {
 	int rc = upload_params(ctx);
 	if (rc) return rc;
 	if (sai2b_launch_reinit(ctx->d_params, ctx->B, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "reinit launch failed");
-	if (sai2b_launch_otg_reinit(ctx->d_params, ctx->B, -1, 0, ctx->stream))
+	if (sai2b_launch_otg_reinit(ctx->d_params, ctx->B, -1, 0, ctx->q, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG reinit launch failed");
 	ctx->goals_dirty = ~0u;
 	ctx->launches += 2;
 	ctx->models_fresh = false;
+	ctx->q_is_pose = true;	// reInitializeTask reads the pose of the current state
 	return SAI2B_OK;
 }
 
@@ -828,6 +845,7 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, ctx->baked_model ? 1 : 0, commit_sh, with_comp, do_torque, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
 	ctx->launches++;
+	if (do_torque) ctx->q_is_pose = true;  // computeTorques caches the tasks' current pose
 	return SAI2B_OK;
 }
 
@@ -975,6 +993,7 @@ extern "C" int sai2b_sim_step(sai2b_ctx* ctx, const double* tau, int on_device, 
 		if ((rc = copy_rows(ctx, ctx->sim_tau, tau, N, 0))) return rc;
 		t = ctx->sim_tau;
 	}
+	if ((rc = keep_pose(ctx))) return rc;
 	if (sai2b_launch_sim(ctx->d_params, ctx->B, t, dt, substeps, with_gravity, nullptr, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "simulation launch failed");
 	ctx->launches++;

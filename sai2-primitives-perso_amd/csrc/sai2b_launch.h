@@ -15,7 +15,9 @@ extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, i
 // internal OTG (sai2b_otg.hip): one update of every enabled generator; (re)initialisation (modes in the kernel's comment)
 extern "C" int sai2b_launch_otg(const sai2b::DevParams* d_params, int B, int* counts, int* list, int parity, int clean_mask,
 								hipStream_t stream);
-extern "C" int sai2b_launch_otg_reinit(const sai2b::DevParams* d_params, int B, int only_task, int mode, hipStream_t stream);
+// q_pose: [7][B] joint positions the tasks' cached poses correspond to (read in mode 1 only)
+extern "C" int sai2b_launch_otg_reinit(const sai2b::DevParams* d_params, int B, int only_task, int mode, const double* q_pose,
+									   hipStream_t stream);
 // simulation harness (sai2b_sim.hip): one control period of rigid-body dynamics, state updated in place
 extern "C" int sai2b_launch_sim(const sai2b::DevParams* d_params, int B, const double* tau, double dt, int substeps,
 								int with_gravity, double* dbg_bias, hipStream_t stream);

@@ -455,11 +455,14 @@ __global__ __launch_bounds__(64) void otg_plan_kernel(const DevParams* __restric
 //   mode 0: reInitializeTask of every task; runs right after reinit_kernel, which has just written
 //           goals = current pose / joint positions.
 //   mode 1: enableInternalOtgAccelerationLimited on task `only_task` whose OTG was off: re-initialise
-//           at the current state (JointTask.cpp:374-376, MotionForceTask.cpp:514-516; the reference
-//           uses the pose cached by the last torque computation, this uses the state buffers), and
-//           for a JointTask zero the input acceleration (OTG_joints::disableJerkLimits, :88-91).
+//           at the task's _current_position / _current_orientation (JointTask.cpp:374-376,
+//           MotionForceTask.cpp:514-516), i.e. the pose of the last torque computation or
+//           re-initialisation: q_pose holds the joint positions of that moment (the host keeps them
+//           when the state buffers move on), and for a JointTask zero the input acceleration
+//           (OTG_joints::disableJerkLimits, :88-91).
 //   mode 2: the same call on a task whose OTG was already on: only the JointTask's zeroing.
-__global__ __launch_bounds__(64) void otg_reinit_kernel(const DevParams* __restrict__ Pp, int only_task, int mode) {
+__global__ __launch_bounds__(64) void otg_reinit_kernel(const DevParams* __restrict__ Pp, int only_task, int mode,
+														const double* __restrict__ q_pose) {
 	const DevParams& P = *Pp;
 	const int B = P.B;
 	const int b = blockIdx.x * 64 + threadIdx.x;
@@ -467,7 +470,7 @@ __global__ __launch_bounds__(64) void otg_reinit_kernel(const DevParams* __restr
 	real q[N];
 	Frames F;
 	if (mode == 1) {
-		UNROLL for (int i = 0; i < N; i++) q[i] = ld(P.q, i, B, b);
+		UNROLL for (int i = 0; i < N; i++) q[i] = ld(q_pose, i, B, b);
 		fk(P.model, q, F);
 	}
 #pragma unroll 1
@@ -536,7 +539,7 @@ extern "C" int sai2b_launch_otg(const sai2b::DevParams* d_params, int B, int* co
 }
 
 extern "C" int sai2b_launch_otg_reinit(const sai2b::DevParams* d_params, int B, int only_task, int mode,
-									   hipStream_t stream) {
-	hipLaunchKernelGGL(sai2b::otg_reinit_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, d_params, only_task, mode);
+									   const double* q_pose, hipStream_t stream) {
+	hipLaunchKernelGGL(sai2b::otg_reinit_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, d_params, only_task, mode, q_pose);
 	return hipGetLastError() == hipSuccess ? 0 : 1;
 }
