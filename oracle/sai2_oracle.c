@@ -1800,6 +1800,20 @@ int oracle_reset_integrators(oracle_ctx* c, int task, int which) {
 	}
 	return 0;
 }
+/* test observer: the four integrators of a MotionForceTask, [12][B]: position, orientation, force, moment */
+int oracle_get_mft_integrators(oracle_ctx* c, int task, double* out) {
+	if (task < 0 || task >= c->T || !c->mft[task]) return fail("not a MotionForceTask");
+	for (int b = 0; b < c->B; b++) {
+		const mft_t* s = &c->mft[task][b];
+		for (int i = 0; i < 3; i++) {
+			out[(0 + i) * c->B + b] = s->integ_pos[i];
+			out[(3 + i) * c->B + b] = s->integ_ori[i];
+			out[(6 + i) * c->B + b] = s->integ_f[i];
+			out[(9 + i) * c->B + b] = s->integ_m[i];
+		}
+	}
+	return 0;
+}
 int oracle_get_jt_desired(oracle_ctx* c, int task, double* q, double* dq, double* ddq) {
 	if (task < 0 || task >= c->T || !c->jt[task]) return fail("not a JointTask");
 	const int k0 = c->cfg[task].task_dof;

@@ -94,6 +94,7 @@ int oracle_get_mft_status(oracle_ctx* ctx, int task, double* pos, double* rot, d
 int oracle_reset_integrators(oracle_ctx* ctx, int task, int which);
 /* desired state of the last computeTorques = goal, or the internal OTG's next state
  * (JointTask.h:182-198 getDesired*, MotionForceTask.h getDesired*); any pointer may be NULL */
+int oracle_get_mft_integrators(oracle_ctx* c, int task, double* out);
 int oracle_get_jt_desired(oracle_ctx* ctx, int task, double* q, double* dq, double* ddq);
 int oracle_get_mft_desired(oracle_ctx* ctx, int task, double* pos, double* rot, double* lin_vel,
 						   double* ang_vel, double* lin_acc, double* ang_acc);

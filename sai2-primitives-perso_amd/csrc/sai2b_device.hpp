@@ -401,6 +401,9 @@ DI void mft_load(const DevTask& t, int B, int b, MftIn& in) {
 // the force/moment ones only in closed-loop mode (:329-331,359-361)
 DI void mft_store_integrators(const DevTask& t, int B, int b, const MftIn& in) {
 	UNROLL for (int k = 0; k < 6; k++) st(t.state, k, B, b, in.integ[k]);
+	// with neither a force nor a moment space mft_load() did not read them (they do not move: sigma = 0)
+	// and they must keep their values for the day a space is parametrised again
+	if ((t.fdim | t.mdim) == 0) return;
 	if (t.cl_force) {
 		UNROLL for (int k = 6; k < 9; k++) st(t.state, k, B, b, in.integ[k]);
 	}

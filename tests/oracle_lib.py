@@ -61,6 +61,7 @@ def lib():
     L.oracle_get_mft_sh_state.argtypes = [vp, i, vp, vp, vp]
     L.oracle_get_mft_task_forces.argtypes = [vp, i, vp, vp]
     L.oracle_get_jt_inertia.argtypes = [vp, i, vp, vp]
+    L.oracle_get_mft_integrators.argtypes = [vp, i, vp]
     L.oracle_get_jt_desired.argtypes = [vp, i, vp, vp, vp]
     L.oracle_get_mft_desired.argtypes = [vp, i] + [vp] * 6
     L.oracle_get_otg_status.argtypes = [vp, i, vp, vp]
@@ -291,6 +292,11 @@ class Oracle:
         out = [np.empty((r, B)) for r in (3, 9, 3, 3, 3, 3)] + [np.empty(B), np.empty(B)]
         assert self.L.oracle_get_mft_status(self.h, task, *[_ptr(x) for x in out]) == 0
         return dict(zip(names, out))
+
+    def get_mft_integrators(self, task):
+        out = np.empty((12, self.B))
+        assert self.L.oracle_get_mft_integrators(self.h, task, _ptr(out)) == 0
+        return out
 
     def reset_integrators(self, task, which=0):
         assert self.L.oracle_reset_integrators(self.h, task, which) == 0

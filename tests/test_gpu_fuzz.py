@@ -48,6 +48,8 @@ def _draw_opts(rng, tasks):
                 o["closed_loop_force"] = bool(rng.integers(2))
                 o["closed_loop_moment"] = bool(rng.integers(2))
                 o["in_compliant_frame"] = bool(rng.integers(2))
+                if o["closed_loop_force"] and o["force_space_dimension"] > 0 and rng.random() < 0.4:
+                    o["passivity"] = True  # POPC on the closed-loop force term
             if rng.random() < 0.25:
                 o["enforce_type_1"] = True
             if rng.random() < 0.15:
@@ -233,16 +235,35 @@ def _event(rng, o, g, tasks, period, env):
     return entry
 
 
-def _event_run_setup(seed):
+def _control(rng, o, g):
+    """one torque computation on both sides: the fused tick, or the reference's two calls (RobotController.cpp:53-74)"""
+    if rng.random() < 0.3:
+        comp = bool(rng.integers(2))
+        for c in (o, g):
+            c.update_task_models()
+        return o.compute_control_torques(with_compensation=comp), g.compute_control_torques(with_compensation=comp)
+    return o.tick(), g.tick()
+
+
+def _event_run_setup(seed, introspection=None):
     rng = np.random.default_rng(77000 + seed)
     name = sorted(SHAPES)[(seed * 5 + 3) % len(SHAPES)]
     tasks = SHAPES[name]
-    B = 128
+    B = (128, 64, 100, 128)[seed % 4]  # 100: ragged last wavefront, the SVD-free kernels are not eligible
     inp = _custom_inputs(tasks, B, seed=seed, singular_fraction=0.05)
     opts = _draw_opts(rng, tasks)
     otg = bool(rng.integers(2))
-    o = ol.Oracle(ol.panda_model(), _configs(ol.task_configs, tasks, opts, otg), B, threads=8)
-    g = pkg.Controller(pkg.panda_model(), _configs(pkg.task_configs, tasks, opts, otg), B, introspection=bool(rng.integers(2)))
+    mo, mg = ol.panda_model(), pkg.panda_model()
+    if seed % 3 == 0:  # not the stock Panda: the kernels take the model from the parameter block
+        dm = np.random.default_rng(seed).uniform(0.8, 1.25, 7)
+        for m in (mo, mg):
+            for i in range(7):
+                m.link_mass[i] *= dm[i]
+            m.joint_xyz[3][0] += 0.01 * dm[0]
+            m.link_com[5][2] += 0.01 * dm[1]
+    o = ol.Oracle(mo, _configs(ol.task_configs, tasks, opts, otg), B, threads=8)
+    drawn = bool(rng.integers(2))
+    g = pkg.Controller(mg, _configs(pkg.task_configs, tasks, opts, otg), B, introspection=drawn if introspection is None else introspection)
     for c in (o, g):
         ol.load_inputs(c, inp)
     return rng, name, tasks, otg, o, g
@@ -265,7 +286,7 @@ def test_random_runtime_events_closed_loop(seed):
     split = np.zeros(B, dtype=bool)
     for period in range(40):
         log.append(_event(rng, o, g, tasks, period, env))
-        tau_o, tau_g = o.tick(), g.tick()
+        tau_o, tau_g = _control(rng, o, g)
         regular = np.ones(B, dtype=bool)
         diverged = np.zeros(B, dtype=bool)  # generator outputs differ
         for u, (k, _) in enumerate(tasks):
@@ -278,17 +299,25 @@ def test_random_runtime_events_closed_loop(seed):
                     diverged |= np.abs(a - b_).reshape(-1, B).max(axis=0) > 1e-6
         den = np.maximum(np.abs(tau_o).max(axis=0), 1e-9)
         e = np.abs(tau_g - tau_o).max(axis=0) / den
-        split |= diverged & (e > np.where(regular, 1e-7, 1e-5))  # torques differ *and* the generators explain it
-        assert split.sum() <= B // 8, (seed, name, log[-6:], np.nonzero(split)[0])
+        split |= diverged & (e > np.where(regular, 1e-8, 1e-5))  # torques differ *and* the generators explain it
+        # (new limits on a Cartesian generator in mid-motion put every moving robot on that threshold at once:
+        # up to ~15 % of a batch have been seen to take the other branch)
+        assert split.sum() <= B // 4, (seed, name, log[-6:], np.nonzero(split)[0])
         e[split] = 0
         log[-1] = log[-1] + (float(f"{e.max():.1e}"),)
         ctx = (seed, name, otg, log[-6:])
-        assert e[regular].max() < 1e-7, (ctx, float(e[regular].max()))  # 40 periods of feedback on unfiltered poses
+        assert e[regular].max() < 1e-8, (ctx, float(e[regular].max()))
         if (~regular).any():
             assert e[~regular].max() < 1e-5, (ctx, float(e[~regular].max()))
         o.sim_step(tau_o, 0.001, 1, with_gravity=env["gravity"])
         g.sim_step(tau_g, 0.001, 1, with_gravity=env["gravity"])
-    qo, dqo = o.get_state()
-    qg, dqg = g.get_state()
-    ok = ~split
-    assert np.abs(qg - qo)[:, ok].max() < 1e-7 and np.abs(dqg - dqo)[:, ok].max() < 1e-4, (seed, name)
+        # The plant is compared and then re-aligned every period: a robot with operational-space inertias of
+        # condition 1e6 otherwise amplifies the 1e-13 of two FP64 implementations by ~1.7x per period (seen:
+        # 5e-9 -> 1e-6 over 10 periods with no event involved), which says nothing about either side. The
+        # controllers' own states (integrators, generators, singularity history) are never re-aligned.
+        qo, dqo = o.get_state()
+        qg, dqg = g.get_state()
+        for mask, tq, tdq in ((~split & regular, 1e-9, 1e-6), (~split & ~regular, 1e-6, 1e-3)):
+            if mask.any():
+                assert np.abs(qg - qo)[:, mask].max() < tq and np.abs(dqg - dqo)[:, mask].max() < tdq, (ctx, "state")
+        g.set_state(qo, dqo)
