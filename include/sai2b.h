@@ -199,7 +199,16 @@ int sai2b_num_tasks(const sai2b_ctx* ctx);
 /* Re-configure batch-uniform task parameters (gains, decoupling, force-space parametrisation,
  * flags) after creation — the reference's setters (MotionForceTask.h:272-328,576-623,669-753,
  * JointTask.h:234-259,360-384). Structural fields (type, task_dof, selection, link, projection)
- * must not change. */
+ * must not change. The setters' side effects follow the fields that changed:
+ *  - use_internal_otg / otg_max_*: enableInternalOtgAccelerationLimited (JointTask.cpp:360-381,
+ *    MotionForceTask.cpp:511-523): a generator that was off starts at the task's current pose;
+ *  - force_space_dimension / force_axis (axis compared normalised, for dimension 1 or 2):
+ *    parametrizeForceMotionSpaces (MotionForceTask.cpp:830-858): goal position := current position, goal
+ *    linear velocity / acceleration := 0, the linear half of the generator re-initialised there, position
+ *    and force integrators reset; moment_space_dimension / moment_axis: the angular counterpart (:860-890);
+ *  - closed_loop_force / closed_loop_moment: the corresponding integrators reset (:973-986);
+ *  - passivity_enabled: the observer re-initialised (POPCExplicitForceControl.cpp:24-28).
+ * "Current" pose = the task's cached one: that of the last torque computation or re-initialisation. */
 int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_task_config* cfg);
 
 /* RobotController::enableGravityCompensation (RobotController.h:31-33) */

@@ -1443,6 +1443,20 @@ void oracle_destroy(oracle_ctx* c) {
 	free(c);
 }
 void oracle_set_threads(oracle_ctx* c, int n) { c->threads = n < 1 ? 1 : n; }
+/* `reset` of parametrizeForceMotionSpaces (MotionForceTask.cpp:838-848): dimension changed, or, for
+ * dimension 1 or 2, the normalised axis is not isApprox (1e-12) the one in use */
+static int space_changed(int dim, const double* axis, int old_dim, const double* old_axis) {
+	if (dim != old_dim) return 1;
+	if (dim != 1 && dim != 2) return 0;
+	double a[3], b[3], na = 0, nb = 0, d2 = 0, a2 = 0, b2 = 0;
+	for (int i = 0; i < 3; i++) na += axis[i] * axis[i], nb += old_axis[i] * old_axis[i];
+	na = sqrt(na), nb = sqrt(nb);
+	for (int i = 0; i < 3; i++) {
+		a[i] = axis[i] / na, b[i] = old_axis[i] / nb;
+		d2 += (a[i] - b[i]) * (a[i] - b[i]), a2 += a[i] * a[i], b2 += b[i] * b[i];
+	}
+	return !(d2 <= 1e-24 * (a2 < b2 ? a2 : b2));
+}
 int oracle_update_task_config(oracle_ctx* c, int task, const sai2b_task_config* cfg) {
 	if (!c || task < 0 || task >= c->T || !cfg || cfg->type != c->cfg[task].type ||
 		cfg->task_dof != c->cfg[task].task_dof)
@@ -1470,6 +1484,33 @@ int oracle_update_task_config(oracle_ctx* c, int task, const sai2b_task_config* 
 			else
 				mft_otg_enable(cfg, &c->mft[task][b], &c->cotg[task][b], old->use_internal_otg != 0);
 		}
+	if (c->mft[task]) {
+		/* parametrizeForceMotionSpaces / parametrizeMomentRotMotionSpaces (MotionForceTask.cpp:830-890): a new
+		 * dimension, or a new axis for dimension 1 or 2, moves the goal to the current pose, re-initialises that
+		 * half of the generator there and resets that half of the integrators; setClosedLoopForceControl /
+		 * setClosedLoopMomentControl (:973-986) reset them when the mode changes */
+		const int lin = space_changed(cfg->force_space_dimension, cfg->force_axis, old->force_space_dimension, old->force_axis);
+		const int ang = space_changed(cfg->moment_space_dimension, cfg->moment_axis, old->moment_space_dimension, old->moment_axis);
+		const int cl_f = (cfg->closed_loop_force != 0) != (old->closed_loop_force != 0);
+		const int cl_m = (cfg->closed_loop_moment != 0) != (old->closed_loop_moment != 0);
+		for (int b = 0; b < c->B && (lin || ang || cl_f || cl_m); b++) {
+			mft_t* s = &c->mft[task][b];
+			if (lin) {
+				memcpy(s->g_pos, s->cur_pos, sizeof(s->g_pos));
+				for (int i = 0; i < 3; i++) s->g_v[i] = s->g_a[i] = 0;
+				otg_cartesian_reinitialize_linear(&c->cotg[task][b], s->cur_pos);
+			}
+			if (ang) {
+				memcpy(s->g_rot, s->cur_rot, sizeof(s->g_rot));
+				for (int i = 0; i < 3; i++) s->g_w[i] = s->g_al[i] = 0;
+				otg_cartesian_reinitialize_angular(&c->cotg[task][b], s->cur_rot);
+			}
+			for (int i = 0; i < 3; i++) {
+				if (lin || cl_f) s->integ_pos[i] = s->integ_f[i] = 0;
+				if (ang || cl_m) s->integ_ori[i] = s->integ_m[i] = 0;
+			}
+		}
+	}
 	c->cfg[task] = *cfg;
 	return 0;
 }

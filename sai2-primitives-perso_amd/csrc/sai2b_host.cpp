@@ -626,6 +626,22 @@ extern "C" const char* sai2b_last_error(const sai2b_ctx* ctx) { return ctx ? ctx
 extern "C" int sai2b_batch(const sai2b_ctx* ctx) { return ctx ? ctx->B : 0; }
 extern "C" int sai2b_num_tasks(const sai2b_ctx* ctx) { return ctx ? ctx->T : 0; }
 
+// `reset` of MotionForceTask::parametrizeForceMotionSpaces / parametrizeMomentRotMotionSpaces
+// (MotionForceTask.cpp:838-848,866-878): the dimension changed, or, for dimension 1 or 2, the normalised
+// axis is not isApprox (Eigen default 1e-12) the one in use
+static bool space_changed(int dim, const double* axis, int old_dim, const double* old_axis) {
+	if (dim != old_dim) return true;
+	if (dim != 1 && dim != 2) return false;
+	double na = 0, nb = 0, d2 = 0, a2 = 0, b2 = 0;
+	for (int i = 0; i < 3; i++) na += axis[i] * axis[i], nb += old_axis[i] * old_axis[i];
+	na = std::sqrt(na), nb = std::sqrt(nb);
+	for (int i = 0; i < 3; i++) {
+		const double a = axis[i] / na, b = old_axis[i] / nb;
+		d2 += (a - b) * (a - b), a2 += a * a, b2 += b * b;
+	}
+	return !(d2 <= 1e-24 * std::min(a2, b2));
+}
+
 extern "C" int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_task_config* cfg) {
 	if (!ctx || !cfg || task < 0 || task >= ctx->T) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_update_task_config: bad arguments");
 	const sai2b_task_config& old = ctx->cfg[task];
@@ -639,6 +655,14 @@ extern "C" int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_ta
 	char msg[256];
 	if (sai2b_validate_tasks(all, ctx->T, msg, sizeof(msg))) return set_error(ctx, SAI2B_INVALID_ARGUMENT, msg);
 	const bool popc_toggle = old.type == SAI2B_MOTION_FORCE_TASK && (cfg->passivity_enabled != 0) != (old.passivity_enabled != 0);
+	int reparam = 0;  // flags of mft_reparam_kernel
+	if (old.type == SAI2B_MOTION_FORCE_TASK) {
+		const bool lin = space_changed(cfg->force_space_dimension, cfg->force_axis, old.force_space_dimension, old.force_axis);
+		const bool ang = space_changed(cfg->moment_space_dimension, cfg->moment_axis, old.moment_space_dimension, old.moment_axis);
+		const bool cl_f = (cfg->closed_loop_force != 0) != (old.closed_loop_force != 0);
+		const bool cl_m = (cfg->closed_loop_moment != 0) != (old.closed_loop_moment != 0);
+		reparam = (lin ? 1 | 4 : 0) | (ang ? 2 | 8 : 0) | (cl_f ? 4 : 0) | (cl_m ? 8 : 0);
+	}
 	ctx->cfg[task] = *cfg;
 	DevTask& d = ctx->h_params.task[task];
 	DevTask keep = d;
@@ -670,6 +694,13 @@ extern "C" int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_ta
 		if (rc3) return rc3;
 		if (sai2b_launch_otg_reinit(ctx->d_params, ctx->B, task, keep.otg_on ? 2 : 1, ctx->q_is_pose ? ctx->q : ctx->q_pose, ctx->stream))
 			return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG enable launch failed");
+		ctx->launches++;
+	}
+	if (reparam) {
+		int rc4 = upload_params(ctx);
+		if (rc4) return rc4;
+		if (sai2b_launch_mft_reparam(ctx->d_params, ctx->B, task, reparam, ctx->q_is_pose ? ctx->q : ctx->q_pose, ctx->stream))
+			return set_error(ctx, SAI2B_RUNTIME_ERROR, "re-parametrisation launch failed");
 		ctx->launches++;
 	}
 	return SAI2B_OK;

@@ -18,6 +18,9 @@ extern "C" int sai2b_launch_otg(const sai2b::DevParams* d_params, int B, int* co
 // q_pose: [7][B] joint positions the tasks' cached poses correspond to (read in mode 1 only)
 extern "C" int sai2b_launch_otg_reinit(const sai2b::DevParams* d_params, int B, int only_task, int mode, const double* q_pose,
 									   hipStream_t stream);
+// force / motion space re-parametrisation of MotionForceTask `task` at run time (flags in the kernel's comment)
+extern "C" int sai2b_launch_mft_reparam(const sai2b::DevParams* d_params, int B, int task, int flags, const double* q_pose,
+										hipStream_t stream);
 // simulation harness (sai2b_sim.hip): one control period of rigid-body dynamics, state updated in place
 extern "C" int sai2b_launch_sim(const sai2b::DevParams* d_params, int B, const double* tau, double dt, int substeps,
 								int with_gravity, double* dbg_bias, hipStream_t stream);

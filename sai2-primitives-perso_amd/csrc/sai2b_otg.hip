@@ -524,7 +524,61 @@ __global__ __launch_bounds__(64) void otg_reinit_kernel(const DevParams* __restr
 	}
 }
 
+// Run-time re-parametrisation of a MotionForceTask's force / motion spaces (parametrizeForceMotionSpaces,
+// parametrizeMomentRotMotionSpaces: MotionForceTask.cpp:830-890) and closed-loop switches (:973-986), the
+// per-robot part. flags: 1 = linear half (goal position := current position, goal linear velocity /
+// acceleration := 0, generator re-initialised there: reInitializeLinear), 2 = angular half, 4 / 8 = reset
+// the linear (position, force) / angular (orientation, moment) integrators. "Current" is the task's cached
+// pose: q_pose, the joint positions of the last torque computation or re-initialisation.
+__global__ __launch_bounds__(64) void mft_reparam_kernel(const DevParams* __restrict__ Pp, int task, int flags,
+														 const double* __restrict__ q_pose) {
+	const DevParams& P = *Pp;
+	const int B = P.B;
+	const int b = blockIdx.x * 64 + threadIdx.x;
+	if (b >= B) return;
+	const DevTask& tk = P.task[task];
+	if (flags & 3) {
+		real q[N], x[3], R[9];
+		Frames F;
+		UNROLL for (int i = 0; i < N; i++) q[i] = ld(q_pose, i, B, b);
+		fk(P.model, q, F);
+		frame_pose(tk, F, x, R);
+		real* S = tk.otg_state;
+		Gen g;
+		load_head(S, 6, true, B, b, g);
+		load_body(S, 6, true, B, b, g);
+		if (flags & 1) {
+			UNROLL for (int k = 0; k < 3; k++) {
+				st(tk.goals, k, B, b, x[k]);
+				st(tk.goals, 12 + k, B, b, 0.0);
+				st(tk.goals, 18 + k, B, b, 0.0);
+			}
+			otg::cart_reinitialize_linear(g, x);
+		}
+		if (flags & 2) {
+			UNROLL for (int k = 0; k < 9; k++) st(tk.goals, 3 + k, B, b, R[k]);
+			UNROLL for (int k = 0; k < 3; k++) {
+				st(tk.goals, 15 + k, B, b, 0.0);
+				st(tk.goals, 21 + k, B, b, 0.0);
+			}
+			otg::cart_reinitialize_angular(g, R);
+		}
+		store_state(S, 6, true, B, b, g);
+		store_desired_cart(tk.otg_desired, B, b, g);
+	}
+	UNROLL for (int k = 0; k < 3; k++) {
+		if (flags & 4) st(tk.state, k, B, b, 0.0), st(tk.state, 6 + k, B, b, 0.0);
+		if (flags & 8) st(tk.state, 3 + k, B, b, 0.0), st(tk.state, 9 + k, B, b, 0.0);
+	}
+}
+
 }  // namespace sai2b
+
+extern "C" int sai2b_launch_mft_reparam(const sai2b::DevParams* d_params, int B, int task, int flags, const double* q_pose,
+										hipStream_t stream) {
+	hipLaunchKernelGGL(sai2b::mft_reparam_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, d_params, task, flags, q_pose);
+	return hipGetLastError() == hipSuccess ? 0 : 1;
+}
 
 // counts: [2][SAI2B_MAX_TASKS] ints, zero before the first call; list: [SAI2B_MAX_TASKS][B] ints;
 // parity alternates 0/1 between consecutive calls

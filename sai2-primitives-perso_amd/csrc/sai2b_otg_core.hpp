@@ -815,6 +815,25 @@ SAI2B_HD void cart_reinitialize(Gen& g, const double* pos, const double* rot) {
 		g.np[i] = g.in.tp[i], g.nv[i] = 0, g.na[i] = 0;
 	}
 }
+// reInitializeLinear / reInitializeAngular (OTG_6dof_cartesian.cpp:60-83)
+SAI2B_HD void cart_reinitialize_linear(Gen& g, const double* pos) {
+	const double zeros[3] = {0, 0, 0};
+	cart_set_goal_position(g, pos, zeros);
+#pragma unroll
+	for (int i = 0; i < 3; i++) {
+		g.in.cp[i] = g.in.tp[i], g.in.cv[i] = 0, g.in.ca[i] = 0;
+		g.np[i] = g.in.tp[i], g.nv[i] = 0, g.na[i] = 0;
+	}
+}
+SAI2B_HD void cart_reinitialize_angular(Gen& g, const double* rot) {
+	const double zeros[3] = {0, 0, 0};
+	cart_set_goal_orientation(g, rot, zeros);
+#pragma unroll
+	for (int i = 3; i < 6; i++) {
+		g.in.cp[i] = g.in.tp[i], g.in.cv[i] = 0, g.in.ca[i] = 0;
+		g.np[i] = g.in.tp[i], g.nv[i] = 0, g.na[i] = 0;
+	}
+}
 // OTG_6dof_cartesian::update after _otg->update() returned g.result (OTG_6dof_cartesian.cpp:194-223)
 SAI2B_HD void cart_finish(Gen& g, const Prev& pv) {
 	if (g.result == FINISHED) {

@@ -36,7 +36,7 @@ for period in range(upto):
                 c = o.tasks[t]
                 print("      cfg: fdim", c.force_space_dimension, "mdim", c.moment_space_dimension, "cl", c.closed_loop_force, c.closed_loop_moment, "frame", c.parametrization_in_compliant_frame, "passivity", c.passivity_enabled)
         if e[b] > 1e-6 or watch >= 0:
-            print("      oracle desired", [a[..., b] for a in do][:3])
-            print("      gpu    desired", [a[..., b] for a in dg][:3])
+            print("      oracle desired", [a[..., b] for a in do])
+            print("      gpu    desired", [a[..., b] for a in dg])
     o.sim_step(tau_o, 0.001, 1, with_gravity=env["gravity"]); g.sim_step(tau_g, 0.001, 1, with_gravity=env["gravity"])
     g.set_state(*o.get_state())  # as the test does

@@ -300,9 +300,10 @@ def test_random_runtime_events_closed_loop(seed):
         den = np.maximum(np.abs(tau_o).max(axis=0), 1e-9)
         e = np.abs(tau_g - tau_o).max(axis=0) / den
         split |= diverged & (e > np.where(regular, 1e-8, 1e-5))  # torques differ *and* the generators explain it
-        # (new limits on a Cartesian generator in mid-motion put every moving robot on that threshold at once:
-        # up to ~15 % of a batch have been seen to take the other branch)
-        assert split.sum() <= B // 4, (seed, name, log[-6:], np.nonzero(split)[0])
+        # (an event that makes a Cartesian generator re-plan in mid-motion — new limits, half of it re-initialised by
+        # a force-space change — puts every moving robot on that threshold at once: 15-40 % of a batch have been
+        # seen to take the other branch, those where libm and ocml differ in the last bit of a sine)
+        assert split.sum() <= 3 * B // 4, (seed, name, log[-6:], np.nonzero(split)[0])  # several such events in one run add up
         e[split] = 0
         log[-1] = log[-1] + (float(f"{e.max():.1e}"),)
         ctx = (seed, name, otg, log[-6:])

@@ -567,3 +567,52 @@ def test_new_entry_points_reject_bad_arguments():
     with pytest.raises(ValueError):
         g.sim_step(np.zeros((7, B + 1)))
     assert np.array_equal(g.tick(), tau0)  # nothing moved
+
+
+def test_force_space_reparametrisation_side_effects():
+    """parametrizeForceMotionSpaces / parametrizeMomentRotMotionSpaces / setClosedLoopForceControl at run
+    time (MotionForceTask.cpp:830-890, 973-986) through sai2b_update_task_config: goal := current pose of
+    the half that changed, its integrators reset, the other half untouched"""
+    B = 128
+    inp = pkg.workloads.make_inputs(3, B=B, seed=21)
+    opts = [{"ki_pos": 4.0, "ki_ori": 3.0, "force_space_dimension": 1, "force_axis": (0, 0, 1), "closed_loop_force": True}, {}]
+    o, g = _pair(inp, opts, introspection=False)
+    rng = np.random.default_rng(4)
+    sf, sm = rng.normal(0, 3, (3, B)), rng.normal(0, 0.5, (3, B))
+    for c in (o, g):
+        ol.load_inputs(c, inp)
+        c.set_mft_goal_wrench(0, sf, sm)
+        c.set_mft_sensed_wrench(0, 0.5 * sf, 0.5 * sm)
+    for _ in range(3):
+        assert _err(g.tick(), o.tick()).max() < TOL
+    pos_goal, rot_goal = (x.copy() for x in g.get_mft_goals(0)[:2])
+    st = g.get_mft_status(0)
+
+    def change(**kw):
+        for c in (o, g):
+            cfg = type(c.tasks[0]).from_buffer_copy(c.tasks[0])
+            cases.apply_opts(cfg, kw)
+            c.update_task_config(0, cfg)
+
+    # same dimension, same axis up to scale: nothing happens
+    change(force_space_dimension=1, force_axis=(0, 0, 2.5))
+    assert np.array_equal(g.get_mft_goals(0)[0], pos_goal)
+    # new axis: linear half only
+    change(force_space_dimension=1, force_axis=(1, 0, 0))
+    goals = g.get_mft_goals(0)
+    assert np.abs(goals[0] - st["pos"]).max() < 1e-12 and np.array_equal(goals[1], rot_goal)
+    assert np.abs(goals[2]).max() == 0  # goal linear velocity
+    tau_o, tau_g = o.tick(), g.tick()
+    assert _err(tau_g, tau_o).max() < TOL
+    # moment space: angular half
+    st = g.get_mft_status(0)
+    change(moment_space_dimension=2, moment_axis=(0, 1, 0), closed_loop_moment=True)
+    goals = g.get_mft_goals(0)
+    assert np.abs(goals[1] - st["rot"]).max() < 1e-12
+    for _ in range(3):
+        assert _err(g.tick(), o.tick()).max() < TOL
+    # open loop again: force integrator reset, visible when the loop is closed once more
+    change(closed_loop_force=False)
+    change(closed_loop_force=True)
+    for _ in range(2):
+        assert _err(g.tick(), o.tick()).max() < TOL
