@@ -287,19 +287,28 @@ public:
 	void setForceControlGains(double kp, double kv, double ki) { gains3(_cfg.kp_force, _cfg.kv_force, _cfg.ki_force, kp, kv, ki, "setForceControlGains"); }
 	void setMomentControlGains(double kp, double kv, double ki) { gains3(_cfg.kp_moment, _cfg.kv_moment, _cfg.ki_moment, kp, kv, ki, "setMomentControlGains"); }
 	// MotionForceTask.cpp:830-890
-	void parametrizeForceMotionSpaces(const int force_space_dimension, const double axis[3] = nullptr) {
+	// returns whether the spaces changed, in which case the goal position is now the current position, the
+	// linear half of the internal OTG restarts there and the position / force integrators are reset
+	// (MotionForceTask.cpp:830-858)
+	bool parametrizeForceMotionSpaces(const int force_space_dimension, const double axis[3] = nullptr) {
 		if (force_space_dimension < 0 || force_space_dimension > 3)
 			throw std::invalid_argument("Force space dimension should be between 0 and 3 in MotionForceTask::parametrizeForceMotionSpaces\n");
+		const int old_dim = _cfg.force_space_dimension;
+		const double old_axis[3] = {_cfg.force_axis[0], _cfg.force_axis[1], _cfg.force_axis[2]};
 		if (force_space_dimension == 1 || force_space_dimension == 2) unitAxis(axis, _cfg.force_axis, "Force or motion axis should be a non singular vector in MotionForceTask::parametrizeForceMotionSpaces\n");
 		_cfg.force_space_dimension = force_space_dimension;
 		syncConfig();
+		return spaceChanged(force_space_dimension, _cfg.force_axis, old_dim, old_axis);
 	}
-	void parametrizeMomentRotMotionSpaces(const int moment_space_dimension, const double axis[3] = nullptr) {
+	bool parametrizeMomentRotMotionSpaces(const int moment_space_dimension, const double axis[3] = nullptr) {
 		if (moment_space_dimension < 0 || moment_space_dimension > 3)
 			throw std::invalid_argument("Moment space dimension should be between 0 and 3 in MotionForceTask::parametrizeMomentRotMotionSpaces\n");
+		const int old_dim = _cfg.moment_space_dimension;
+		const double old_axis[3] = {_cfg.moment_axis[0], _cfg.moment_axis[1], _cfg.moment_axis[2]};
 		if (moment_space_dimension == 1 || moment_space_dimension == 2) unitAxis(axis, _cfg.moment_axis, "Moment or rot motion axis should be a non singular vector in MotionForceTask::parametrizeMomentRotMotionSpaces\n");
 		_cfg.moment_space_dimension = moment_space_dimension;
 		syncConfig();
+		return spaceChanged(moment_space_dimension, _cfg.moment_axis, old_dim, old_axis);
 	}
 	void setClosedLoopForceControl(const bool on = true) {
 		_cfg.closed_loop_force = on;
@@ -443,6 +452,14 @@ protected:
 		if (p < 0 || v < 0 || i < 0) throw std::invalid_argument(std::string("all gains should be positive or zero in MotionForceTask::") + fn + "\n");
 		for (int k = 0; k < 3; k++) kp[k] = p, kv[k] = v, ki[k] = i;
 		syncConfig();
+	}
+	// `reset` of MotionForceTask.cpp:838-848 (the library applies the same rule)
+	static bool spaceChanged(int dim, const double* axis, int old_dim, const double* old_axis) {
+		if (dim != old_dim) return true;
+		if (dim != 1 && dim != 2) return false;
+		double d2 = 0, a2 = 0, b2 = 0;
+		for (int k = 0; k < 3; k++) d2 += (axis[k] - old_axis[k]) * (axis[k] - old_axis[k]), a2 += axis[k] * axis[k], b2 += old_axis[k] * old_axis[k];
+		return !(d2 <= 1e-24 * std::min(a2, b2));
 	}
 	static void unitAxis(const double* a, double* out, const char* msg) {
 		const double n = a ? std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) : 0.0;

@@ -640,31 +640,37 @@ class MotionForceTask(_TaskBase):
     def setMomentControlGains(self, kp, kv, ki):
         self._set3(("kp_moment", "kv_moment", "ki_moment"), (kp, kv, ki), "setMomentControlGains")
 
-    def parametrizeForceMotionSpaces(self, force_space_dimension, axis=(0, 0, 1)):
-        if not 0 <= force_space_dimension <= 3:
-            raise ValueError("Force space dimension should be between 0 and 3 in MotionForceTask::parametrizeForceMotionSpaces\n")
-        a = np.asarray(axis, dtype=float)
-        if force_space_dimension in (1, 2):
+    def _parametrize(self, dim_field, axis_field, dim, axis, dim_msg, axis_msg):
+        """-> whether the space changed (`reset` of MotionForceTask.cpp:838-848); the library then moves that half of
+        the goal to the current pose, restarts that half of the internal OTG there and resets its integrators"""
+        if not 0 <= dim <= 3:
+            raise ValueError(dim_msg)
+        old_dim, old_axis = getattr(self._cfg, dim_field), np.array(getattr(self._cfg, axis_field)[:])
+        if dim in (1, 2):
+            a = np.asarray(axis, dtype=float)
             if np.linalg.norm(a) < 1e-2:
-                raise ValueError("Force or motion axis should be a non singular vector in MotionForceTask::parametrizeForceMotionSpaces\n")
+                raise ValueError(axis_msg)
             a = a / np.linalg.norm(a)
             for i in range(3):
-                self._cfg.force_axis[i] = a[i]
-        self._cfg.force_space_dimension = int(force_space_dimension)
+                getattr(self._cfg, axis_field)[i] = a[i]
+        setattr(self._cfg, dim_field, int(dim))
         self._sync_cfg()
+        if dim != old_dim:
+            return True
+        if dim not in (1, 2):
+            return False
+        new_axis = np.array(getattr(self._cfg, axis_field)[:])
+        return not (np.sum((new_axis - old_axis) ** 2) <= 1e-24 * min(np.sum(new_axis ** 2), np.sum(old_axis ** 2)))
+
+    def parametrizeForceMotionSpaces(self, force_space_dimension, axis=(0, 0, 1)):
+        return self._parametrize("force_space_dimension", "force_axis", force_space_dimension, axis,
+                                 "Force space dimension should be between 0 and 3 in MotionForceTask::parametrizeForceMotionSpaces\n",
+                                 "Force or motion axis should be a non singular vector in MotionForceTask::parametrizeForceMotionSpaces\n")
 
     def parametrizeMomentRotMotionSpaces(self, moment_space_dimension, axis=(0, 0, 1)):
-        if not 0 <= moment_space_dimension <= 3:
-            raise ValueError("Moment space dimension should be between 0 and 3 in MotionForceTask::parametrizeMomentRotMotionSpaces\n")
-        a = np.asarray(axis, dtype=float)
-        if moment_space_dimension in (1, 2):
-            if np.linalg.norm(a) < 1e-2:
-                raise ValueError("Moment or rot motion axis should be a non singular vector in MotionForceTask::parametrizeMomentRotMotionSpaces\n")
-            a = a / np.linalg.norm(a)
-            for i in range(3):
-                self._cfg.moment_axis[i] = a[i]
-        self._cfg.moment_space_dimension = int(moment_space_dimension)
-        self._sync_cfg()
+        return self._parametrize("moment_space_dimension", "moment_axis", moment_space_dimension, axis,
+                                 "Moment space dimension should be between 0 and 3 in MotionForceTask::parametrizeMomentRotMotionSpaces\n",
+                                 "Moment or rot motion axis should be a non singular vector in MotionForceTask::parametrizeMomentRotMotionSpaces\n")
 
     def setClosedLoopForceControl(self, on=True):
         self._cfg.closed_loop_force = int(on)

@@ -343,6 +343,14 @@ def test_facade_mirrors_reference_api():
     o = ol.Oracle(ol.panda_model(), ol.task_configs(inp["tasks"]), B, threads=8)
     ol.load_inputs(o, inp)
     assert _err(tau, o.tick()).max() < TOL
+    # run-time re-parametrisation reports whether anything changed (MotionForceTask.cpp:830-858) and, if so,
+    # the goal of that half is the current pose
+    assert mft.parametrizeForceMotionSpaces(1, (0, 0, 1)) is True
+    assert mft.parametrizeForceMotionSpaces(1, (0, 0, 3.0)) is False
+    assert mft.parametrizeForceMotionSpaces(1, (0, 1, 0)) is True
+    assert mft.parametrizeMomentRotMotionSpaces(0) is False
+    assert np.abs(mft.getGoalPosition() - mft.getCurrentPosition()).max() < 1e-12
+    assert mft.parametrizeForceMotionSpaces(0) is True
     with pytest.raises(ValueError):
         jt.setGoalPosition(np.zeros((3, B)))
     with pytest.raises(ValueError, match="same robot model"):
