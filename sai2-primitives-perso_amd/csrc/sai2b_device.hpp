@@ -392,8 +392,12 @@ DI void mft_load(const DevTask& t, int B, int b, MftIn& in) {
 				in.s_f[k] = ld(t.sensed, k, B, b);
 				in.s_m[k] = ld(t.sensed, 3 + k, B, b);
 			}
-			UNROLL for (int k = 6; k < 12; k++) in.integ[k] = ld(t.state, k, B, b);
 		}
+	}
+	// read whenever they are written back (mft_store_integrators), also with no force / moment space
+	// parametrised (sigma = 0: they do not move, and keep their values for when a space comes back)
+	if (t.cl_force || t.cl_moment) {
+		UNROLL for (int k = 6; k < 12; k++) in.integ[k] = ld(t.state, k, B, b);
 	}
 }
 
@@ -401,9 +405,6 @@ DI void mft_load(const DevTask& t, int B, int b, MftIn& in) {
 // the force/moment ones only in closed-loop mode (:329-331,359-361)
 DI void mft_store_integrators(const DevTask& t, int B, int b, const MftIn& in) {
 	UNROLL for (int k = 0; k < 6; k++) st(t.state, k, B, b, in.integ[k]);
-	// with neither a force nor a moment space mft_load() did not read them (they do not move: sigma = 0)
-	// and they must keep their values for the day a space is parametrised again
-	if ((t.fdim | t.mdim) == 0) return;
 	if (t.cl_force) {
 		UNROLL for (int k = 6; k < 9; k++) st(t.state, k, B, b, in.integ[k]);
 	}
