@@ -40,7 +40,7 @@ def _draw_opts(rng, tasks):
                 o.update(ki_pos=float(rng.uniform(1, 20)), ki_ori=float(rng.uniform(1, 20)))
             if rng.random() < 0.4:
                 o["velocity_saturation"] = (float(rng.uniform(0.05, 0.4)), float(rng.uniform(0.3, 1.5)))
-            if prm["partial"] is None and rng.random() < 0.5:  # force / moment spaces on full tasks
+            if rng.random() < 0.5:  # force / moment spaces (on partial tasks too: sigma is projected, MotionForceTask.cpp:893-960)
                 o["force_space_dimension"] = int(rng.integers(0, 4))
                 o["moment_space_dimension"] = int(rng.integers(0, 4))
                 o["force_axis"] = tuple(rng.normal(size=3))
@@ -157,7 +157,7 @@ def _mutate(cfg, rng_state, all_cfgs):
         else:
             for i in range(c.task_dof):
                 c.saturation_velocity[i] = rng.uniform(0.3, 1.5)
-    elif what == 4 and c.type == pkg.MOTION_FORCE_TASK and c.pos_range == 3 and c.ori_range == 3:  # force space
+    elif what == 4 and c.type == pkg.MOTION_FORCE_TASK:  # force space
         cases.apply_opts(c, {"force_space_dimension": int(rng.integers(4)), "moment_space_dimension": int(rng.integers(4)),
                              "force_axis": tuple(rng.normal(size=3)), "moment_axis": tuple(rng.normal(size=3)),
                              "closed_loop_force": bool(rng.integers(2)), "closed_loop_moment": bool(rng.integers(2)),
