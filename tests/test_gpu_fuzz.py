@@ -329,6 +329,17 @@ def test_random_runtime_events_closed_loop(seed):
             assert e[regular].max() < 1e-8, (ctx, float(e[regular].max()))
         if (~regular).any():  # inside a blending region the handler's own history (40 periods of it) carries 1e-6 along
             assert e[~regular].max() < 1e-4, (ctx, float(e[~regular].max()))
+        if period % 8 == 7:  # what the examples read from their tasks between ticks
+            for u, (k, _) in enumerate(tasks):
+                ok = ~split
+                if k == "mft":
+                    so_, sg_ = o.get_mft_status(u), g.get_mft_status(u)
+                    for key in so_:
+                        scale = 1e-4 if ("sensed" in key or "error" in key) and not regular.all() else 1e-9
+                        assert np.abs(so_[key] - sg_[key])[..., ok].max() < max(scale, 1e-9 * np.abs(so_[key]).max()), (ctx, key)
+                if o.tasks[u].use_internal_otg:
+                    for a, b_ in zip(o.get_otg_status(u), g.get_otg_status(u)):
+                        assert np.array_equal(a[ok], b_[ok]), (ctx, "otg status", u)
         o.sim_step(tau_o, 0.001, 1, with_gravity=env["gravity"])
         g.sim_step(tau_g, 0.001, 1, with_gravity=env["gravity"])
         # The plant is compared and then re-aligned every period: a robot with operational-space inertias of
