@@ -264,6 +264,9 @@ enum sai2b_buffer {
 	SAI2B_BUF_SENSED = 4, /* per MFT task: [6][B] sensor-frame force, moment */
 	SAI2B_BUF_STATE = 5	  /* per task persistent state, see DESIGN.md */
 };
+/* (A producer that writes q through SAI2B_BUF_Q bypasses the bookkeeping of the tasks' cached pose: an OTG
+ * enabled / a space re-parametrised after such a write and before the next tick starts from the state as
+ * written, not from the pose of the last torque computation.) */
 void* sai2b_device_buffer(sai2b_ctx* ctx, int which, int task);
 
 /* Optional per-robot outputs of the last tick (debug / observers such as
