@@ -1088,7 +1088,7 @@ DI void mft_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B
 }
 
 // JointTask::updateTaskModel + computeTorques(tau_prec) for one robot (JointTask.cpp:218-356)
-template <bool DEBUG>
+template <bool DEBUG, bool RANGE_ONLY = false>
 DI void jt_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B, int b, bool first, bool last,
 				bool with_comp, bool do_torque, real* Nprec, real* tau_total, Chain& chain) {
 	real Jp[N * N];
@@ -1161,6 +1161,7 @@ DI void jt_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B,
 		}
 	}
 	if (t.otg_gated && !do_torque) st(t.otg_state, OTG_ACTIVE, B, b, zero_range ? 0.0 : 1.0);  // read by otg_kernel
+	if constexpr (RANGE_ONLY) return;  // last gated task of the range pass: its inertias and nullspace are not needed
 	real tau[N];
 	UNROLL for (int i = 0; i < N; i++) tau[i] = 0;
 	real Ntask[N * N];

@@ -859,7 +859,7 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 	const int fast = fast_kind(ctx);
 	if (do_torque && gated) {
 		// which robots' gated tasks are active this tick: the task models of the current state, nothing committed
-		if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, 0, 0, /*commit_sh=*/0, with_comp, /*do_torque=*/0, nullptr, nullptr, 0, ctx->stream))
+		if (sai2b_launch_range_pass(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, with_comp, ctx->stream))
 			return set_error(ctx, SAI2B_RUNTIME_ERROR, "task-range pass launch failed");
 		ctx->launches++;
 	}

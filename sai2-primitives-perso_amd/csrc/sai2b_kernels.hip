@@ -16,7 +16,10 @@ namespace sai2b {
 // Generic tick: Jacobi-SVD based, any hierarchy (the reference's control flow, projector form).
 // fb_count != NULL: the fallback pass behind tick_fast_kernel — lane i of the grid takes robot
 // fb_list[i] for i < *fb_count (the robots the SVD-free kernel declined, compacted), the rest exits.
-template <bool DEBUG>
+// RANGE: the pass ahead of the generator kernels that only decides which robots' gated JointTasks have a
+// range this tick (DevTask::otg_gated): nothing after the last such task is needed. A separate
+// instantiation, so that the tick proper compiles as it did without it.
+template <bool DEBUG, bool RANGE = false>
 __global__ __launch_bounds__(64) void tick_kernel(const DevParams* __restrict__ Pp, int commit_sh, int with_comp,
 													 int do_torque, const int* __restrict__ fb_count,
 													 const int* __restrict__ fb_list) {
@@ -72,12 +75,20 @@ __global__ __launch_bounds__(64) void tick_kernel(const DevParams* __restrict__ 
 	chain.ok = !DEBUG;
 	chain.wrows = 0;
 	UNROLL for (int i = 0; i < N * N; i++) chain.W[i] = 0;
+	int n_run = P.n_tasks;
+	if constexpr (RANGE) {
+		n_run = 0;
+		for (int t = 0; t < P.n_tasks; t++)
+			if (P.task[t].otg_gated) n_run = t + 1;
+	}
 #pragma unroll 1
-	for (int t = 0; t < P.n_tasks; t++) {
+	for (int t = 0; t < n_run; t++) {
 		const DevTask& tk = P.task[t];
 		const bool first = (t == 0), last = (t == P.n_tasks - 1);
 		if (tk.type == SAI2B_MOTION_FORCE_TASK)
 			mft_task<DEBUG>(P, tk, rc, B, b, first, last, commit_sh != 0, do_torque != 0, Nprec, tau, chain);
+		else if (RANGE && t == n_run - 1)
+			jt_task<DEBUG, true>(P, tk, rc, B, b, first, last, with_comp != 0, do_torque != 0, Nprec, tau, chain);
 		else
 			jt_task<DEBUG>(P, tk, rc, B, b, first, last, with_comp != 0, do_torque != 0, Nprec, tau, chain);
 	}
@@ -240,6 +251,17 @@ extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int de
 	} else {
 		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, nullptr, nullptr);
 	}
+	return (int)hipGetLastError();
+}
+
+// the range pass of hierarchies with gated generators (same DEBUG variant as the tick that follows, so that
+// both take the same range decisions)
+extern "C" int sai2b_launch_range_pass(const sai2b::DevParams* d_params, int B, int debug, int with_comp, hipStream_t stream) {
+	const dim3 grid((B + 63) / 64), block(64);
+	if (debug)
+		hipLaunchKernelGGL((sai2b::tick_kernel<true, true>), grid, block, 0, stream, d_params, 0, with_comp, 0, nullptr, nullptr);
+	else
+		hipLaunchKernelGGL((sai2b::tick_kernel<false, true>), grid, block, 0, stream, d_params, 0, with_comp, 0, nullptr, nullptr);
 	return (int)hipGetLastError();
 }
 

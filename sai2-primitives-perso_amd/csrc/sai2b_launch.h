@@ -6,6 +6,7 @@
 
 extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int commit_sh,
 								 int with_comp, int do_torque, int* fb_counts, int* fb_list, int parity, hipStream_t stream);
+extern "C" int sai2b_launch_range_pass(const sai2b::DevParams* d_params, int B, int debug, int with_comp, hipStream_t stream);
 extern "C" int sai2b_launch_reinit(const sai2b::DevParams* d_params, int B, hipStream_t stream);
 // one kernel of a (fast) tick on its own, for per-kernel timing: part 0 = first kernel, part 1 = the
 // generic kernel over the work list of the SVD-free one. fb_counts: 2 ints, zero before the first
