@@ -1024,8 +1024,10 @@ extern "C" int sai2b_sim_step(sai2b_ctx* ctx, const double* tau, int on_device, 
 		if ((rc = copy_rows(ctx, ctx->sim_tau, tau, N, 0))) return rc;
 		t = ctx->sim_tau;
 	}
-	if ((rc = keep_pose(ctx))) return rc;
-	if (sai2b_launch_sim(ctx->d_params, ctx->B, t, dt, substeps, with_gravity, nullptr, ctx->stream))
+	// the kernel saves the pose the tasks cached (q_pose) on its way in, when the state buffer still holds it
+	double* q_keep = ctx->q_is_pose ? ctx->q_pose : nullptr;
+	ctx->q_is_pose = false;
+	if (sai2b_launch_sim(ctx->d_params, ctx->B, t, dt, substeps, with_gravity, nullptr, q_keep, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "simulation launch failed");
 	ctx->launches++;
 	ctx->models_fresh = false;
@@ -1045,7 +1047,7 @@ extern "C" int sai2b_get_bias(sai2b_ctx* ctx, int with_gravity, double* bias) {
 	if (rc) return rc;
 	if (!ctx->sim_tau && (rc = dev_alloc(ctx, &ctx->sim_tau, (size_t)N * ctx->B))) return rc;
 	// a zero-length step leaves the state as it is and writes the bias vector of the current state
-	if (sai2b_launch_sim(ctx->d_params, ctx->B, nullptr, 0.0, 1, with_gravity, ctx->sim_tau, ctx->stream))
+	if (sai2b_launch_sim(ctx->d_params, ctx->B, nullptr, 0.0, 1, with_gravity, ctx->sim_tau, nullptr, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "simulation launch failed");
 	return fetch_rows(ctx, ctx->sim_tau, 0, N, bias);
 }

@@ -24,6 +24,6 @@ extern "C" int sai2b_launch_mft_reparam(const sai2b::DevParams* d_params, int B,
 										hipStream_t stream);
 // simulation harness (sai2b_sim.hip): one control period of rigid-body dynamics, state updated in place
 extern "C" int sai2b_launch_sim(const sai2b::DevParams* d_params, int B, const double* tau, double dt, int substeps,
-								int with_gravity, double* dbg_bias, hipStream_t stream);
+								int with_gravity, double* dbg_bias, double* q_keep, hipStream_t stream);
 // observers of a MotionForceTask between ticks: out [26][B] (rows in sai2b_sim.hip: mft_status_kernel)
 extern "C" int sai2b_launch_mft_status(const sai2b::DevParams* d_params, int B, int task, double* out, hipStream_t stream);

@@ -82,8 +82,11 @@ DI void bias_forces(const MD& md, const Frames& Fr, const real* dq, bool with_gr
 	}
 }
 
+// q_keep != NULL: the joint positions as they are on entry are saved there first (the pose the tasks cached at
+// their last torque computation: see q_pose in sai2b_host.cpp)
 __global__ __launch_bounds__(64) void sim_kernel(const DevParams* __restrict__ Pp, const real* __restrict__ tau,
-												 real dt, int substeps, int with_gravity, real* __restrict__ dbg_bias) {
+												 real dt, int substeps, int with_gravity, real* __restrict__ dbg_bias,
+												 real* __restrict__ q_keep) {
 	const DevParams& P = *Pp;
 	const int B = P.B;
 	const int b = blockIdx.x * 64 + threadIdx.x;
@@ -93,6 +96,7 @@ __global__ __launch_bounds__(64) void sim_kernel(const DevParams* __restrict__ P
 		q[i] = ld(P.q, i, B, b);
 		dq[i] = ld(P.dq, i, B, b);
 		tq[i] = tau ? ld(tau, i, B, b) : 0.0;
+		if (q_keep) st(q_keep, i, B, b, q[i]);
 	}
 	const real h = dt / substeps;
 #pragma unroll 1
@@ -180,8 +184,8 @@ extern "C" int sai2b_launch_mft_status(const sai2b::DevParams* d_params, int B, 
 }
 
 extern "C" int sai2b_launch_sim(const sai2b::DevParams* d_params, int B, const double* tau, double dt, int substeps,
-								int with_gravity, double* dbg_bias, hipStream_t stream) {
+								int with_gravity, double* dbg_bias, double* q_keep, hipStream_t stream) {
 	hipLaunchKernelGGL(sai2b::sim_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, d_params, tau, dt, substeps, with_gravity,
-					   dbg_bias);
+					   dbg_bias, q_keep);
 	return hipGetLastError() == hipSuccess ? 0 : 1;
 }
