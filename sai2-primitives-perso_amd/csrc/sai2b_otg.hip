@@ -221,8 +221,11 @@ DI void load_traj(const real* S, int n, bool cart, int B, int b, Gen& g) {
 		otg::Prof& p = g.traj.prof[d];
 		if (d < n) {
 			const int r = OTG_TRAJ + d * OTG_TRAJ_STRIDE;
-			f.brake_t = ld(S, r, B, b), f.brake_a = ld(S, r + 1, B, b), f.brake_p = ld(S, r + 2, B, b);
-			f.brake_v = ld(S, r + 3, B, b), f.p0 = ld(S, r + 4, B, b), f.v0 = ld(S, r + 5, B, b);
+			f.brake_t = ld(S, r, B, b), f.p0 = ld(S, r + 4, B, b), f.v0 = ld(S, r + 5, B, b);
+			f.brake_a = f.brake_p = f.brake_v = 0.0;
+			if (f.brake_t > 0.0) {	// the rest of a brake pre-trajectory is read only where there is one (at_time)
+				f.brake_a = ld(S, r + 1, B, b), f.brake_p = ld(S, r + 2, B, b), f.brake_v = ld(S, r + 3, B, b);
+			}
 			p.t0 = ld(S, r + 6, B, b), p.t1 = ld(S, r + 7, B, b), p.t2 = ld(S, r + 8, B, b), p.t6 = ld(S, r + 9, B, b);
 			p.a0 = ld(S, r + 10, B, b), p.a2 = ld(S, r + 11, B, b), p.a6 = ld(S, r + 12, B, b);
 			p.dur = ((p.t0 + p.t1) + p.t2) + p.t6;
