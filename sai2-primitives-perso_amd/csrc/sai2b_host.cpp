@@ -809,11 +809,12 @@ extern "C" int sai2b_reinitialize(sai2b_ctx* ctx) {
 	return SAI2B_OK;
 }
 
-// eligibility of the SVD-free path (sai2b_fast.hpp): [full MFT] or [full MFT, full JT]; whole wavefronts only
+// eligibility of the SVD-free path (sai2b_fast.hpp): [full MFT] or [full MFT, full JT] (any batch size: a robot
+// the kernel declines goes to the generic kernel on its own, lanes past the batch just exit)
 static int fast_kind(const sai2b_ctx* ctx) {
 	// the passivity observer mutates per-robot state inside the law: generic kernel only
 	if (ctx->cfg[0].passivity_enabled && ctx->cfg[0].closed_loop_force) return 0;
-	if (ctx->no_fast_path || ctx->T > 2 || ctx->B % 64 != 0 || ctx->cfg[0].type != SAI2B_MOTION_FORCE_TASK ||
+	if (ctx->no_fast_path || ctx->T > 2 || ctx->cfg[0].type != SAI2B_MOTION_FORCE_TASK ||
 		!ctx->h_params.task[0].full_projection || ctx->h_params.task[0].rank != 6)
 		return 0;
 	if (ctx->T == 1) return 1;

@@ -256,7 +256,7 @@ def _event_run_setup(seed, introspection=None):
     rng = np.random.default_rng(77000 + seed)
     name = sorted(SHAPES)[(seed * 5 + 3) % len(SHAPES)]
     tasks = SHAPES[name]
-    B = (128, 64, 100, 128)[seed % 4]  # 100: ragged last wavefront, the SVD-free kernels are not eligible
+    B = (128, 64, 100, 128)[seed % 4]  # 100: ragged last wavefront
     inp = _custom_inputs(tasks, B, seed=seed, singular_fraction=0.05)
     opts = _draw_opts(rng, tasks)
     otg = bool(rng.integers(2))

@@ -359,13 +359,20 @@ def test_facade_mirrors_reference_api():
 
 @pytest.mark.parametrize("B", [1, 63, 65, 100, 128])
 def test_ragged_batch_sizes(B):
-    """batches that are not a multiple of the wavefront size (tail lanes masked; the SVD-free kernel
-    needs whole wavefronts, so ragged batches run the generic kernel) and the smallest batch"""
+    """batches that are not a multiple of the wavefront size (tail lanes exit; the SVD-free kernel takes them
+    too, a declined robot going to the generic kernel on its own) and the smallest batch"""
     inp = pkg.workloads.make_inputs(3, B=B, seed=500 + B)
+    q = inp["q"].copy()
+    q[3, B - 1] = -0.0715  # the very last robot singular: through the work list from a partial wavefront
+    inp["q"] = q
     o, g = _pair(inp, introspection=False)
     ol.load_inputs(o, inp)
     ol.load_inputs(g, inp)
-    assert _err(g.tick(), o.tick()).max() < TOL
+    for _ in range(2):
+        e = _err(g.tick(), o.tick())
+        assert e[: B - 1].max(initial=0.0) < TOL and e[B - 1] < 1e-6
+        assert g.fallback_count() >= 1
+    assert g.profile_tick(2)[1] > 0  # the SVD-free kernel ran, with the generic one behind it
 
 
 def test_runtime_reconfiguration_and_error_paths():
