@@ -80,7 +80,7 @@ def _configs(make, tasks, opts, otg, frames=None):
 
 
 # SAI2B_FUZZ_SEEDS=<n> widens the sweep for an exploratory run (2 000 seeds of each test were run clean when this was written)
-@pytest.mark.parametrize("seed", range(int(os.environ.get("SAI2B_FUZZ_SEEDS", "24"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SAI2B_FUZZ_SEEDS", "48"))))
 def test_random_configuration_closed_loop(seed):
     rng = np.random.default_rng(9000 + seed)
     name = sorted(SHAPES)[seed % len(SHAPES)]
@@ -287,7 +287,7 @@ def _event_run_setup(seed, introspection=None):
     return rng, name, tasks, otg, o, g
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("SAI2B_FUZZ_SEEDS", "16"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SAI2B_FUZZ_SEEDS", "32"))))
 def test_random_runtime_events_closed_loop(seed):
     """40 closed-loop periods with random run-time events applied to both sides in lock-step: new goals,
     task reconfiguration (_mutate), reinitialisation, integrator resets, new sensor readings, state jumps,
