@@ -82,6 +82,32 @@ def cpu_baseline(inp, seconds=8.0):
     }
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this same script (rank r on
+    GPU r, rendezvous on 127.0.0.1), relay their output (rank 0 prints the JSON line) and return the worst
+    exit code. Runs before anything initialises the GPU in this process."""
+    import socket
+    import subprocess
+
+    n = args.gpus
+    if not args.single_device and torch.cuda.device_count() < n:
+        print(f"bench.py: --gpus {n} but only {torch.cuda.device_count()} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,11 +120,22 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher. Nothing has touched the GPU yet
+        # (device_count() does not initialise it), the ranks are fresh child processes, never an exec.
+        raise SystemExit(spawn_ranks(args))
+
     import sai2_primitives_perso_amd as pkg
 
     rank, local_rank, world = pkg.sharding.env_rank()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     if args.single_device:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible "
+                         "(--single-device rehearses every rank on cuda:0)")
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")

@@ -53,6 +53,7 @@ inline void check(sai2b_ctx* ctx, int rc) {
 }  // namespace detail
 
 class RobotController;
+class TemplateTask;
 
 // Stands where the reference takes std::shared_ptr<Sai2Model::Sai2Model>
 class BatchedRobotModel {
@@ -90,10 +91,12 @@ public:
 
 private:
 	friend class RobotController;
+	friend class TemplateTask;
 	void assign(Batch& dst, const Batch& src) {
 		if (src.size() != dst.size()) throw std::invalid_argument("state must have 7 * batch entries ([7][B])");
 		dst = src;
 	}
+	std::vector<sai2b_ctx*> _standalone;  // contexts of tasks driven on their own (TemplateTask-level calls)
 	int _batch, _device;
 	sai2b_robot_model _model;
 	sai2b_urdf_links _links;
@@ -105,13 +108,47 @@ private:
 // reference src/tasks/TemplateTask.h:25-123
 class TemplateTask {
 public:
-	TemplateTask(std::shared_ptr<BatchedRobotModel>& robot, const TaskType task_type) : _robot(robot), _task_type(task_type) {}
-	virtual ~TemplateTask() = default;
+	TemplateTask(std::shared_ptr<BatchedRobotModel>& robot, const TaskType task_type)
+		: _robot(robot), _task_type(task_type), _q_construction(robot->q()) {}
+	virtual ~TemplateTask() { releaseOwnContext(); }
+	TemplateTask(const TemplateTask&) = delete;
+	TemplateTask& operator=(const TemplateTask&) = delete;
+	// ---- the reference's plugin interface (TemplateTask.h:42-88). A task that is not attached to a
+	// RobotController runs on a context of its own (created on the first call that needs the device); the
+	// caller chains the nullspaces as in examples/04-task_and_redundancy.cpp:141-150,188-189.
+	// N_prec: [49][B] row-major inside the component index (TemplateTask.h:42)
+	void updateTaskModel(const Batch& N_prec) {
+		checkRows(N_prec, 49, "N_prec");
+		detail::check(ctx(), sai2b_task_update_model(ctx(), index(), N_prec.data(), 0));
+		_task_level = true;
+	}
+	// first task of a hierarchy: N_prec = identity without materialising it
+	void updateTaskModel() {
+		detail::check(ctx(), sai2b_task_update_model(ctx(), index(), nullptr, 0));
+		_task_level = true;
+	}
+	// this task's torques [7][B] (TemplateTask.h:49)
+	Batch computeTorques() {
+		Batch tau(7 * B());
+		detail::check(ctx(), sai2b_task_compute_torques(ctx(), index(), nullptr, tau.data(), 0));
+		return tau;
+	}
+	// with the feed-forward compensation of the previous tasks' torques (TemplateTask.h:58)
+	Batch computeTorques(const Batch& tau_prec) {
+		checkRows(tau_prec, 7, "tau_prec");
+		Batch tau(7 * B());
+		detail::check(ctx(), sai2b_task_compute_torques(ctx(), index(), tau_prec.data(), tau.data(), 0));
+		return tau;
+	}
+	void reInitializeTask() { detail::check(ctx(), sai2b_task_reinitialize(ctx(), index())); }  // TemplateTask.h:65
+	Batch getTaskNullspace() const { return nullspace(0); }			  // TemplateTask.h:73
+	Batch getPreviousTasksNullspace() const { return nullspace(1); }  // TemplateTask.h:81
 	const std::shared_ptr<BatchedRobotModel>& getConstRobotModel() const { return _robot; }
 	double getLoopTimestep() const { return _cfg.loop_timestep; }
 	TaskType getTaskType() const { return _task_type; }
 	std::string getTaskName() const { return _cfg.name; }
-	// N * N_prec of the last tick, [49][B] (TemplateTask.h:88); needs RobotController::enableIntrospection
+	// N * N_prec, [49][B] (TemplateTask.h:88): of the last updateTaskModel(); for a task that only ever ran inside
+	// a RobotController, of the controller's last tick (needs RobotController::enableIntrospection)
 	inline Batch getTaskAndPreviousNullspace() const;
 	void setDynamicDecouplingType(const DynamicDecouplingType type) {
 		_cfg.dynamic_decoupling_type = type;
@@ -122,10 +159,29 @@ public:
 		syncConfig();
 	}
 	const sai2b_task_config& config() const { return _cfg; }
+	// the device context this task runs in (the controller's, or its own when driven on its own)
+	sai2b_ctx* context() const { return ctx(); }
 
 protected:
 	friend class RobotController;
 	inline void syncConfig();
+	// the context this task lives in and its index there: the controller's, or its own
+	inline sai2b_ctx* ctx() const;
+	int index() const { return _owner ? _index : 0; }
+	Batch nullspace(int which) const {
+		Batch out(49 * B());
+		double* p[3] = {nullptr, nullptr, nullptr};
+		p[which] = out.data();
+		detail::check(ctx(), sai2b_task_get_nullspaces(ctx(), index(), p[0], p[1], p[2]));
+		return out;
+	}
+	void releaseOwnContext() {
+		if (!_own_ctx) return;
+		auto& v = _robot->_standalone;
+		v.erase(std::remove(v.begin(), v.end(), _own_ctx), v.end());
+		sai2b_destroy(_own_ctx);
+		_own_ctx = nullptr;
+	}
 	size_t B() const { return (size_t)_robot->batch(); }
 	void checkRows(const Batch& v, size_t rows, const char* what) const {
 		if (v.size() != rows * B()) throw std::invalid_argument(std::string(what) + " size not consistent with task dof and batch\n");
@@ -136,6 +192,9 @@ protected:
 	sai2b_task_config _cfg;
 	RobotController* _owner = nullptr;
 	int _index = -1;
+	mutable sai2b_ctx* _own_ctx = nullptr;
+	Batch _q_construction;	// the reference constructs a task at the model's state of that moment
+	bool _task_level = false;
 };
 
 // reference src/tasks/JointTask.h
@@ -216,6 +275,10 @@ public:
 		syncConfig();
 	}
 	bool getInternalOtgEnabled() const { return _cfg.use_internal_otg != 0; }
+	// JointTask.h:144-160: [task_dof][B]
+	Batch getGoalPosition() const { return goal(0); }
+	Batch getGoalVelocity() const { return goal(1); }
+	Batch getGoalAcceleration() const { return goal(2); }
 	// JointTask.h:182-198: goal, or the OTG's next state; [task_dof][B]
 	inline Batch getDesiredPosition() const;
 	inline Batch getDesiredVelocity() const;
@@ -224,6 +287,13 @@ public:
 protected:
 	inline void flushGoals() override;
 	inline Batch desired(int which) const;
+	Batch goal(int which) const {
+		Batch out((size_t)_cfg.task_dof * B());
+		double* p[3] = {nullptr, nullptr, nullptr};
+		p[which] = out.data();
+		detail::check(ctx(), sai2b_get_jt_goals(ctx(), index(), p[0], p[1], p[2]));
+		return out;
+	}
 	Batch _goal_q, _goal_dq, _goal_ddq;
 };
 
@@ -428,10 +498,43 @@ public:
 	inline void resetIntegrators();
 	inline void resetIntegratorsLinear();
 	inline void resetIntegratorsAngular();
-	void enforceType1Strategy(const bool on = true) {
-		_cfg.enforce_type_1_strategy = on;
+	void enforceType1Strategy(const bool on = true) { handleAllSingularitiesAsType1(on); }
+	// MotionForceTask.h:697 -> SingularityHandler.h:131-133
+	void handleAllSingularitiesAsType1(const bool flag) {
+		_cfg.enforce_type_1_strategy = flag;
 		syncConfig();
 	}
+	// MotionForceTask.h:706 -> SingularityHandler.h:140-142; q_des [7][B]
+	void setType1Posture(const Batch& q_des) {
+		checkRows(q_des, 7, "type 1 posture");
+		detail::check(ctx(), sai2b_set_mft_type1_posture(ctx(), index(), q_des.data(), 0));
+	}
+	// MotionForceTask.h:281-304: per-axis gains, with and without the sign check
+	void setPosControlGains(const double kp[3], const double kv[3], const double ki[3]) { gains3v(_cfg.kp_pos, _cfg.kv_pos, _cfg.ki_pos, kp, kv, ki, true, "setPosControlGains"); }
+	void setOriControlGains(const double kp[3], const double kv[3], const double ki[3]) { gains3v(_cfg.kp_ori, _cfg.kv_ori, _cfg.ki_ori, kp, kv, ki, true, "setOriControlGains"); }
+	void setPosControlGainsUnsafe(const double kp[3], const double kv[3], const double ki[3]) { gains3v(_cfg.kp_pos, _cfg.kv_pos, _cfg.ki_pos, kp, kv, ki, false, "setPosControlGainsUnsafe"); }
+	void setOriControlGainsUnsafe(const double kp[3], const double kv[3], const double ki[3]) { gains3v(_cfg.kp_ori, _cfg.kv_ori, _cfg.ki_ori, kp, kv, ki, false, "setOriControlGainsUnsafe"); }
+	// one entry when the gains are isotropic, three otherwise (MotionForceTask.cpp:651-666)
+	std::vector<PIDGains> getPosControlGains() const { return gainsOut(_cfg.kp_pos, _cfg.kv_pos, _cfg.ki_pos); }
+	std::vector<PIDGains> getOriControlGains() const { return gainsOut(_cfg.kp_ori, _cfg.kv_ori, _cfg.ki_ori); }
+	std::vector<PIDGains> getForceControlGains() const { return {PIDGains(_cfg.kp_force[0], _cfg.kv_force[0], _cfg.ki_force[0])}; }
+	std::vector<PIDGains> getMomentControlGains() const { return {PIDGains(_cfg.kp_moment[0], _cfg.kv_moment[0], _cfg.ki_moment[0])}; }
+	// MotionForceTask.h:610-613 (MotionForceTask.cpp:892-971): [9][B] row-major, for the state as it is now
+	Batch sigmaForce() const { return sigma(0); }
+	Batch sigmaPosition() const { return sigma(1); }
+	Batch sigmaMoment() const { return sigma(2); }
+	Batch sigmaOrientation() const { return sigma(3); }
+	// MotionForceTask.h:127-146: J dq of the state as it is now, [3][B]
+	Batch getCurrentLinearVelocity() const { return velocity(0); }
+	Batch getCurrentAngularVelocity() const { return velocity(1); }
+	// MotionForceTask.h:266: [6][B], of the controller's last tick (RobotController::enableIntrospection)
+	Batch getUnitMassForce() const {
+		Batch out(6 * B());
+		detail::check(ctx(), sai2b_get_mft_task_forces(ctx(), index(), out.data(), nullptr));
+		return out;
+	}
+	std::vector<double> getForceMotionSingleAxis() const { return {_cfg.force_axis[0], _cfg.force_axis[1], _cfg.force_axis[2]}; }
+	std::vector<double> getMomentRotMotionSingleAxis() const { return {_cfg.moment_axis[0], _cfg.moment_axis[1], _cfg.moment_axis[2]}; }
 	void enableSingularityHandling(const bool on = true) {
 		_cfg.enforce_handling_strategy = on;
 		syncConfig();
@@ -447,6 +550,31 @@ protected:
 		checkRows(v, rows, what);
 		dst = v;
 		flushGoals();
+	}
+	void gains3v(double* kp, double* kv, double* ki, const double* p, const double* v, const double* i, bool checked, const char* fn) {
+		for (int k = 0; k < 3 && checked; k++)
+			if (p[k] < 0 || v[k] < 0 || i[k] < 0) throw std::invalid_argument(std::string("all gains should be positive or zero in MotionForceTask::") + fn + "\n");
+		for (int k = 0; k < 3; k++) kp[k] = p[k], kv[k] = v[k], ki[k] = i[k];
+		if (!checked) _cfg.unsafe_motion_gains = 1;
+		syncConfig();
+	}
+	static std::vector<PIDGains> gainsOut(const double* kp, const double* kv, const double* ki) {
+		const bool iso = kp[0] == kp[1] && kp[1] == kp[2] && kv[0] == kv[1] && kv[1] == kv[2] && ki[0] == ki[1] && ki[1] == ki[2];
+		std::vector<PIDGains> g;
+		for (int k = 0; k < (iso ? 1 : 3); k++) g.emplace_back(kp[k], kv[k], ki[k]);
+		return g;
+	}
+	Batch sigma(int which) const {
+		Batch out(9 * B());
+		double* p[4] = {nullptr, nullptr, nullptr, nullptr};
+		p[which] = out.data();
+		detail::check(ctx(), sai2b_get_mft_sigma(ctx(), index(), p[0], p[1], p[2], p[3]));
+		return out;
+	}
+	Batch velocity(int which) const {
+		Batch out(3 * B());
+		detail::check(ctx(), sai2b_get_mft_velocity(ctx(), index(), which == 0 ? out.data() : nullptr, which == 1 ? out.data() : nullptr));
+		return out;
 	}
 	void gains3(double* kp, double* kv, double* ki, double p, double v, double i, const char* fn) {
 		if (p < 0 || v < 0 || i < 0) throw std::invalid_argument(std::string("all gains should be positive or zero in MotionForceTask::") + fn + "\n");
@@ -491,6 +619,7 @@ public:
 		detail::check(_ctx, sai2b_set_state(_ctx, robot->q().data(), robot->dq().data(), 0));
 		detail::check(_ctx, sai2b_reinitialize(_ctx));	// tasks are constructed at the model's current state
 		for (size_t i = 0; i < _tasks.size(); i++) {
+			_tasks[i]->releaseOwnContext();
 			_tasks[i]->_owner = this;
 			_tasks[i]->_index = (int)i;
 			_task_names.push_back(_tasks[i]->getTaskName());
@@ -554,20 +683,38 @@ private:
 // ---- inline members that need RobotController
 inline void BatchedRobotModel::updateModel() {
 	if (_controller) detail::check(_controller->ctx(), sai2b_set_state(_controller->ctx(), _q.data(), _dq.data(), 0));
+	for (sai2b_ctx* c : _standalone) detail::check(c, sai2b_set_state(c, _q.data(), _dq.data(), 0));
+}
+inline sai2b_ctx* TemplateTask::ctx() const {
+	if (_owner) return _owner->ctx();
+	if (!_own_ctx) {
+		_own_ctx = sai2b_create(&_robot->model(), &_cfg, 1, _robot->batch(), _robot->device());
+		if (!_own_ctx) {
+			const std::string msg = sai2b_last_error(nullptr);
+			if (msg.find("HIP") != std::string::npos || msg.find("hip") != std::string::npos) throw std::runtime_error(msg);
+			throw std::invalid_argument(msg);
+		}
+		_robot->_standalone.push_back(_own_ctx);
+		// goals := the pose the task was constructed at, then follow the robot
+		detail::check(_own_ctx, sai2b_set_state(_own_ctx, _q_construction.data(), nullptr, 0));
+		detail::check(_own_ctx, sai2b_reinitialize(_own_ctx));
+		detail::check(_own_ctx, sai2b_set_state(_own_ctx, _robot->q().data(), _robot->dq().data(), 0));
+		const_cast<TemplateTask*>(this)->flushGoals();
+	}
+	return _own_ctx;
 }
 inline void TemplateTask::syncConfig() {
-	if (_owner) detail::check(_owner->ctx(), sai2b_update_task_config(_owner->ctx(), _index, &_cfg));
+	if (_owner || _own_ctx) detail::check(ctx(), sai2b_update_task_config(ctx(), index(), &_cfg));
 }
 inline Batch TemplateTask::getTaskAndPreviousNullspace() const {
-	if (!_owner) throw std::invalid_argument("task is not attached to a RobotController");
+	if (_task_level || !_owner) return nullspace(2);
 	Batch out(49 * B());
 	detail::check(_owner->ctx(), sai2b_get_task_nullspace(_owner->ctx(), _index, out.data()));
 	return out;
 }
 inline Batch MotionForceTask::getSigmaValues() const {
-	if (!_owner) throw std::invalid_argument("task is not attached to a RobotController");
 	Batch out(6 * B());
-	detail::check(_owner->ctx(), sai2b_get_mft_singularity(_owner->ctx(), _index, out.data(), nullptr, nullptr));
+	detail::check(ctx(), sai2b_get_mft_singularity(ctx(), index(), out.data(), nullptr, nullptr));
 	return out;
 }
 // Stands in for Sai2Simulation in the examples' loops (examples/05-...cpp:215-236: setJointTorques,
@@ -577,7 +724,12 @@ inline Batch MotionForceTask::getSigmaValues() const {
 class BatchedSimulation {
 public:
 	explicit BatchedSimulation(RobotController& controller, const double timestep = 0.001, const int substeps = 1)
-		: _controller(controller), _dt(timestep), _substeps(substeps) {
+		: BatchedSimulation(controller.ctx(), timestep, substeps) {}
+	// manual hierarchies (no RobotController, examples 01 / 04): the dynamics run in the context of any one of the
+	// robot's tasks; feed the result back with robot->setQ(sim.getJointPositions()) ... updateModel() as the examples do
+	explicit BatchedSimulation(const TemplateTask& task, const double timestep = 0.001, const int substeps = 1)
+		: BatchedSimulation(task.context(), timestep, substeps) {}
+	BatchedSimulation(sai2b_ctx* ctx, const double timestep, const int substeps) : _c(ctx), _dt(timestep), _substeps(substeps) {
 		if (timestep <= 0 || substeps < 1) throw std::invalid_argument("simulation timestep must be positive");
 	}
 	void setTimestep(const double dt) {
@@ -591,7 +743,7 @@ public:
 	inline Batch getJointVelocities() const;
 
 private:
-	RobotController& _controller;
+	sai2b_ctx* _c;
 	double _dt;
 	int _substeps;
 	bool _gravity = false;
@@ -599,12 +751,11 @@ private:
 };
 
 inline Batch MotionForceTask::status(int which) const {
-	if (!_owner) throw std::invalid_argument("task is not attached to a RobotController");
 	const size_t rows[8] = {3, 9, 3, 3, 3, 3, 1, 1};
 	Batch out(rows[which] * B());
 	double* p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	p[which] = out.data();
-	detail::check(_owner->ctx(), sai2b_get_mft_status(_owner->ctx(), _index, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]));
+	detail::check(ctx(), sai2b_get_mft_status(ctx(), index(), p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]));
 	return out;
 }
 inline Batch MotionForceTask::getCurrentPosition() const { return status(0); }
@@ -626,46 +777,34 @@ inline std::vector<bool> MotionForceTask::goalOrientationReached(const double to
 	return r;
 }
 inline Batch MotionForceTask::getGoalPosition() const {
-	if (!_owner) throw std::invalid_argument("task is not attached to a RobotController");
 	Batch out(3 * B());
-	detail::check(_owner->ctx(), sai2b_get_mft_goals(_owner->ctx(), _index, out.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+	detail::check(ctx(), sai2b_get_mft_goals(ctx(), index(), out.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
 	return out;
 }
 inline Batch MotionForceTask::getGoalOrientation() const {
-	if (!_owner) throw std::invalid_argument("task is not attached to a RobotController");
 	Batch out(9 * B());
-	detail::check(_owner->ctx(), sai2b_get_mft_goals(_owner->ctx(), _index, nullptr, out.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+	detail::check(ctx(), sai2b_get_mft_goals(ctx(), index(), nullptr, out.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
 	return out;
 }
-inline void JointTask::resetIntegrators() {
-	if (_owner) detail::check(_owner->ctx(), sai2b_reset_integrators(_owner->ctx(), _index, 0));
-}
-inline void MotionForceTask::resetIntegrators() {
-	if (_owner) detail::check(_owner->ctx(), sai2b_reset_integrators(_owner->ctx(), _index, 0));
-}
-inline void MotionForceTask::resetIntegratorsLinear() {
-	if (_owner) detail::check(_owner->ctx(), sai2b_reset_integrators(_owner->ctx(), _index, 1));
-}
-inline void MotionForceTask::resetIntegratorsAngular() {
-	if (_owner) detail::check(_owner->ctx(), sai2b_reset_integrators(_owner->ctx(), _index, 2));
-}
+inline void JointTask::resetIntegrators() { detail::check(ctx(), sai2b_reset_integrators(ctx(), index(), 0)); }
+inline void MotionForceTask::resetIntegrators() { detail::check(ctx(), sai2b_reset_integrators(ctx(), index(), 0)); }
+inline void MotionForceTask::resetIntegratorsLinear() { detail::check(ctx(), sai2b_reset_integrators(ctx(), index(), 1)); }
+inline void MotionForceTask::resetIntegratorsAngular() { detail::check(ctx(), sai2b_reset_integrators(ctx(), index(), 2)); }
 inline Batch JointTask::desired(int which) const {
-	if (!_owner) throw std::invalid_argument("task is not attached to a RobotController");
 	Batch out((size_t)_cfg.task_dof * B());
 	double* p[3] = {nullptr, nullptr, nullptr};
 	p[which] = out.data();
-	detail::check(_owner->ctx(), sai2b_get_jt_desired(_owner->ctx(), _index, p[0], p[1], p[2]));
+	detail::check(ctx(), sai2b_get_jt_desired(ctx(), index(), p[0], p[1], p[2]));
 	return out;
 }
 inline Batch JointTask::getDesiredPosition() const { return desired(0); }
 inline Batch JointTask::getDesiredVelocity() const { return desired(1); }
 inline Batch JointTask::getDesiredAcceleration() const { return desired(2); }
 inline Batch MotionForceTask::desired(int which) const {
-	if (!_owner) throw std::invalid_argument("task is not attached to a RobotController");
 	Batch out((which == 1 ? 9 : 3) * B());
 	double* p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	p[which] = out.data();
-	detail::check(_owner->ctx(), sai2b_get_mft_desired(_owner->ctx(), _index, p[0], p[1], p[2], p[3], p[4], p[5]));
+	detail::check(ctx(), sai2b_get_mft_desired(ctx(), index(), p[0], p[1], p[2], p[3], p[4], p[5]));
 	return out;
 }
 inline Batch MotionForceTask::getDesiredPosition() const { return desired(0); }
@@ -675,34 +814,34 @@ inline Batch MotionForceTask::getDesiredAngularVelocity() const { return desired
 inline Batch MotionForceTask::getDesiredLinearAcceleration() const { return desired(4); }
 inline Batch MotionForceTask::getDesiredAngularAcceleration() const { return desired(5); }
 inline void BatchedSimulation::integrate() {
-	sai2b_ctx* c = _controller.ctx();
+	sai2b_ctx* c = _c;
 	if (!_tau.empty() && _tau.size() != 7 * (size_t)sai2b_batch(c)) throw std::invalid_argument("joint torques must have shape [7][B]");
 	detail::check(c, sai2b_sim_step(c, _tau.empty() ? nullptr : _tau.data(), 0, _dt, _substeps, _gravity ? 1 : 0));
 	_tau.clear();
 }
 inline Batch BatchedSimulation::getJointPositions() const {
-	Batch q(7 * (size_t)sai2b_batch(_controller.ctx()));
-	detail::check(_controller.ctx(), sai2b_get_state(_controller.ctx(), q.data(), nullptr));
+	Batch q(7 * (size_t)sai2b_batch(_c));
+	detail::check(_c, sai2b_get_state(_c, q.data(), nullptr));
 	return q;
 }
 inline Batch BatchedSimulation::getJointVelocities() const {
-	Batch dq(7 * (size_t)sai2b_batch(_controller.ctx()));
-	detail::check(_controller.ctx(), sai2b_get_state(_controller.ctx(), nullptr, dq.data()));
+	Batch dq(7 * (size_t)sai2b_batch(_c));
+	detail::check(_c, sai2b_get_state(_c, nullptr, dq.data()));
 	return dq;
 }
 inline void JointTask::flushGoals() {
-	if (!_owner) return;
+	if (!_owner && !_own_ctx) return;
 	auto p = [](const Batch& b) { return b.empty() ? nullptr : b.data(); };
-	detail::check(_owner->ctx(), sai2b_set_jt_goals(_owner->ctx(), _index, p(_goal_q), p(_goal_dq), p(_goal_ddq), 0));
+	detail::check(ctx(), sai2b_set_jt_goals(ctx(), index(), p(_goal_q), p(_goal_dq), p(_goal_ddq), 0));
 	_goal_q.clear(), _goal_dq.clear(), _goal_ddq.clear();
 }
 inline void MotionForceTask::flushGoals() {
-	if (!_owner) return;
+	if (!_owner && !_own_ctx) return;
 	auto p = [](const Batch& b) { return b.empty() ? nullptr : b.data(); };
-	sai2b_ctx* c = _owner->ctx();
-	detail::check(c, sai2b_set_mft_goals(c, _index, p(_g[0]), p(_g[1]), p(_g[2]), p(_g[3]), p(_g[4]), p(_g[5]), 0));
-	if (!_g[6].empty() || !_g[7].empty()) detail::check(c, sai2b_set_mft_goal_wrench(c, _index, p(_g[6]), p(_g[7]), 0));
-	if (!_g[8].empty() || !_g[9].empty()) detail::check(c, sai2b_set_mft_sensed_wrench(c, _index, p(_g[8]), p(_g[9]), 0));
+	sai2b_ctx* c = ctx();
+	detail::check(c, sai2b_set_mft_goals(c, index(), p(_g[0]), p(_g[1]), p(_g[2]), p(_g[3]), p(_g[4]), p(_g[5]), 0));
+	if (!_g[6].empty() || !_g[7].empty()) detail::check(c, sai2b_set_mft_goal_wrench(c, index(), p(_g[6]), p(_g[7]), 0));
+	if (!_g[8].empty() || !_g[9].empty()) detail::check(c, sai2b_set_mft_sensed_wrench(c, index(), p(_g[8]), p(_g[9]), 0));
 	for (auto& b : _g) b.clear();
 }
 

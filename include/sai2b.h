@@ -124,6 +124,10 @@ typedef struct sai2b_task_config {
 	double otg_max_velocity[SAI2B_DOF], otg_max_acceleration[SAI2B_DOF]; /* JointTask, per task dof */
 	double otg_max_linear_velocity, otg_max_linear_acceleration;		 /* MotionForceTask */
 	double otg_max_angular_velocity, otg_max_angular_acceleration;
+
+	/* MotionForceTask::setPosControlGainsUnsafe / setOriControlGainsUnsafe (MotionForceTask.h:283,304;
+	 * MotionForceTask.cpp:630-649): nonzero skips the sign check of the motion gains */
+	int unsafe_motion_gains;
 } sai2b_task_config;
 
 typedef struct sai2b_ctx sai2b_ctx;
@@ -250,10 +254,48 @@ int sai2b_compute_control_torques_ex(sai2b_ctx* ctx, double* tau, int on_device,
 /* update_task_models + compute_control_torques for the current state in ONE fused launch: the
  * batched hot path. Enqueued on the ctx stream; does not synchronise when tau == NULL. */
 int sai2b_tick(sai2b_ctx* ctx, double* tau, int on_device);
+/* ------------------------------------------------------------------ task-level plugin interface
+ * The reference's tasks can be driven one by one, without a RobotController, through the virtuals of
+ * TemplateTask (src/tasks/TemplateTask.h:42-88) — examples/01-joint_control.cpp:131-191,
+ * examples/04-task_and_redundancy.cpp:141-150,188-206, examples/18. The same calls on task `task` of a ctx
+ * (a ctx with ONE task is a standalone task object; tasks of one ctx share the robot state of
+ * sai2b_set_state). The caller chains the nullspaces itself:
+ *     sai2b_task_update_model(ctx, 0, NULL, 0);                 // N_prec = identity
+ *     sai2b_task_get_nullspaces(ctx, 0, NULL, NULL, N01);       // getTaskAndPreviousNullspace()
+ *     sai2b_task_update_model(ctx, 1, N01, 0);
+ *     sai2b_task_compute_torques(ctx, 0, NULL, tau0, 0);        // computeTorques()
+ *     sai2b_task_compute_torques(ctx, 1, tau0, tau1, 0);        // computeTorques(tau_prec)
+ * Nothing is assumed about the tasks above: range decisions always take the SVD path. */
+/* TemplateTask::updateTaskModel(N_prec) (TemplateTask.h:42; JointTask.cpp:218-283, MotionForceTask.cpp:247-268).
+ * N_prec: [n*n][B] row-major inside the component index, NULL = identity. The singularity bookkeeping of a
+ * MotionForceTask (SingularityHandler.cpp:230-295) advances once per call, as in the reference. */
+int sai2b_task_update_model(sai2b_ctx* ctx, int task, const double* N_prec, int on_device);
+/* TemplateTask::computeTorques() (tau_prec == NULL, TemplateTask.h:49) and computeTorques(tau_prec) (:58): the
+ * task's own torques [n][B] under the N_prec of the last sai2b_task_update_model (identity when there was none,
+ * the value a task is constructed with). Integrators and the task's internal OTG advance as in the reference.
+ * A MotionForceTask ignores tau_prec (its compensation term is identically zero: MotionForceTask.cpp:270-276
+ * with the never-assigned _Lambda, :140); a JointTask subtracts Jp^T R M_partial R^T S M^-1 tau_prec
+ * (JointTask.cpp:285-292). Task models are those of the CURRENT state (never stale, see DESIGN.md "split API").
+ * tau may be NULL (the result stays on the device). */
+int sai2b_task_compute_torques(sai2b_ctx* ctx, int task, const double* tau_prec, double* tau, int on_device);
+/* TemplateTask::reInitializeTask (TemplateTask.h:65; JointTask.cpp:91-107, MotionForceTask.cpp:204-245) of one task */
+int sai2b_task_reinitialize(sai2b_ctx* ctx, int task);
+/* TemplateTask::getTaskNullspace / getPreviousTasksNullspace / getTaskAndPreviousNullspace (TemplateTask.h:73-88)
+ * of the last sai2b_task_update_model / sai2b_task_compute_torques of that task: host arrays [n*n][B], any NULL */
+int sai2b_task_get_nullspaces(sai2b_ctx* ctx, int task, double* N_task, double* N_prec, double* N_total);
+
 /* wait for everything enqueued on the ctx stream */
 int sai2b_synchronize(sai2b_ctx* ctx);
 /* the hipStream_t the ctx launches on (as void*) */
 void* sai2b_stream(sai2b_ctx* ctx);
+/* Stream contract for DEVICE-pointer arguments (every `on_device != 0` above and below). The ctx works on its own
+ * non-blocking stream. A device input is read after everything the caller has enqueued on ITS stream up to the
+ * call (the producer kernels) and the read is finished before anything the caller enqueues on that stream after
+ * the call returns (so the buffer may be overwritten at once); a device result (tau with on_device) is complete
+ * when the call returns. The caller's stream is the legacy default stream unless set here (pass the hipStream_t,
+ * e.g. torch.cuda.current_stream().cuda_stream). Host-pointer arguments are always complete on return.
+ * Buffers handed out by sai2b_device_buffer() are outside this contract: order them with sai2b_stream(). */
+int sai2b_set_caller_stream(sai2b_ctx* ctx, void* stream);
 
 /* Device-resident ctx buffers, for zero-copy producers/consumers. `which`: */
 enum sai2b_buffer {
@@ -281,6 +323,11 @@ int sai2b_get_task_torques(sai2b_ctx* ctx, int task, double* tau_task);
 /* MFT: singular values [6][B], blending alpha [B], split index (non-singular rank) [B] as doubles */
 int sai2b_get_mft_singularity(sai2b_ctx* ctx, int task, double* sigma, double* alpha,
 							  double* ns_rank);
+/* MFT, no introspection needed: the SingularityHandler's state after the last model update
+ * (SingularityHandler.h:211-215) per robot, int [B] each, any may be NULL: number of singular directions
+ * (_singularity_types.size(), 0 = fully non-singular), _type_1_counter, _type_2_counter. */
+int sai2b_get_mft_singularity_state(sai2b_ctx* ctx, int task, int* n_singular, int* type_1_count,
+									int* type_2_count);
 /* MFT: unit-mass motion force and force-related terms of the last tick, [6][B] each — what
  * MotionForceTask::getUnitMassForce and the observers of POPCBilateralTeleoperation.cpp:81-92,172-182
  * read (MotionForceTask.cpp:478-487) */
@@ -310,6 +357,18 @@ int sai2b_get_bias(sai2b_ctx* ctx, int with_gravity, double* bias);
 int sai2b_get_mft_status(sai2b_ctx* ctx, int task, double* pos, double* rot, double* sensed_force_world,
 						 double* sensed_moment_world, double* pos_error, double* ori_error,
 						 double* pos_error_norm, double* ori_error_norm);
+/* MotionForceTask::getCurrentLinearVelocity / getCurrentAngularVelocity (MotionForceTask.h:127-146; J dq of
+ * the state as it is now, MotionForceTask.cpp:293-298): host [3][B] each, any NULL */
+int sai2b_get_mft_velocity(sai2b_ctx* ctx, int task, double* linear_velocity, double* angular_velocity);
+/* MotionForceTask::sigmaForce / sigmaPosition / sigmaMoment / sigmaOrientation (MotionForceTask.h:610-613,
+ * MotionForceTask.cpp:892-971) for the state as it is now (they depend on the robot only when the spaces are
+ * parametrised in the compliant frame): host [9][B] row-major each, any NULL */
+int sai2b_get_mft_sigma(sai2b_ctx* ctx, int task, double* sigma_force, double* sigma_position,
+						double* sigma_moment, double* sigma_orientation);
+/* MotionForceTask::setType1Posture (MotionForceTask.h:706 -> SingularityHandler.h:140-142): the posture the
+ * type-1 singularity strategy holds, [n][B]; kept until the handler next refreshes it
+ * (SingularityHandler.cpp:233-236), as in the reference */
+int sai2b_set_mft_type1_posture(sai2b_ctx* ctx, int task, const double* q_des, int on_device);
 /* getGoalPosition ... getGoalMoment (MotionForceTask.h:214-247,  JointTask.h:144-160) */
 int sai2b_get_mft_goals(sai2b_ctx* ctx, int task, double* pos, double* rot, double* lin_vel, double* ang_vel,
 						double* lin_acc, double* ang_acc, double* force, double* moment);

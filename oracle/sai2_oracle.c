@@ -1647,6 +1647,79 @@ int oracle_tick(oracle_ctx* c, double* tau) {
 	return 0;
 }
 
+/* ---- task-level plugin interface (TemplateTask.h:42-88): one task driven on its own, the caller chaining
+ * the nullspaces (examples/04-task_and_redundancy.cpp:141-150,188-189; examples/01-joint_control.cpp:131-191) ---- */
+int oracle_task_update_model(oracle_ctx* c, int task, const double* N_prec) {
+	if (task < 0 || task >= c->T) return fail("bad task");
+#pragma omp parallel for num_threads(c->threads) schedule(static)
+	for (int b = 0; b < c->B; b++) {
+		double Np[49];
+		if (N_prec)
+			for (int i = 0; i < 49; i++) Np[i] = N_prec[i * c->B + b];
+		else
+			eye(N7, Np);
+		ensure_model(c, b);
+		if (c->jt[task])
+			jt_update(&c->cfg[task], &c->robots[b], &c->jt[task][b], Np); /* JointTask.cpp:218-283 */
+		else
+			mft_update(c, &c->cfg[task], &c->robots[b], &c->mft[task][b], Np); /* MotionForceTask.cpp:247-268 */
+	}
+	return 0;
+}
+/* computeTorques() (tau_prec == NULL) / computeTorques(tau_prec) with the task's cached model */
+int oracle_task_compute_torques(oracle_ctx* c, int task, const double* tau_prec, double* tau) {
+	if (task < 0 || task >= c->T) return fail("bad task");
+#pragma omp parallel for num_threads(c->threads) schedule(static)
+	for (int b = 0; b < c->B; b++) {
+		robot_t* r = &c->robots[b];
+		double tt[N7], comp[N7], tp[N7];
+		ensure_model(c, b);
+		if (c->jt[task]) {
+			jt_torques(&c->cfg[task], r, &c->jt[task][b], &c->jotg[task][b], tt);
+			if (tau_prec) { /* JointTask.cpp:285-292 */
+				for (int k = 0; k < N7; k++) tp[k] = tau_prec[k * c->B + b];
+				jt_compensation(&c->cfg[task], r, &c->jt[task][b], tp, comp);
+				for (int k = 0; k < N7; k++) tt[k] -= comp[k];
+			}
+			memcpy(c->jt[task][b].tau, tt, sizeof(tt));
+		} else { /* MotionForceTask.cpp:270-276: the compensation term is identically zero (App. B-1) */
+			mft_torques(c, &c->cfg[task], r, &c->mft[task][b], &c->cotg[task][b], tt);
+			memcpy(c->mft[task][b].tau, tt, sizeof(tt));
+		}
+		if (tau)
+			for (int k = 0; k < N7; k++) tau[k * c->B + b] = tt[k];
+	}
+	return 0;
+}
+int oracle_task_reinitialize(oracle_ctx* c, int task) {
+	if (task < 0 || task >= c->T) return fail("bad task");
+	for (int b = 0; b < c->B; b++) {
+		ensure_model(c, b);
+		if (c->jt[task])
+			jt_reinit(&c->cfg[task], &c->robots[b], &c->jt[task][b], &c->jotg[task][b]);
+		else {
+			mft_reinit(&c->cfg[task], &c->robots[b], &c->mft[task][b], &c->cotg[task][b]);
+			sh_init(c, &c->mft[task][b]);
+		}
+	}
+	return 0;
+}
+int oracle_task_get_nullspaces(oracle_ctx* c, int task, double* N, double* N_prec, double* N_total) {
+	if (task < 0 || task >= c->T) return fail("bad task");
+	for (int b = 0; b < c->B; b++) {
+		const double* n = c->jt[task] ? c->jt[task][b].N : c->mft[task][b].N;
+		const double* np = c->jt[task] ? c->jt[task][b].N_prec : c->mft[task][b].N_prec;
+		double T[49];
+		mm(N7, N7, N7, n, np, T);
+		for (int i = 0; i < 49; i++) {
+			if (N) N[i * c->B + b] = n[i];
+			if (N_prec) N_prec[i * c->B + b] = np[i];
+			if (N_total) N_total[i * c->B + b] = T[i];
+		}
+	}
+	return 0;
+}
+
 /* ---- getters ---- */
 int oracle_get_task_nullspace(oracle_ctx* c, int task, double* out) {
 	if (task < 0 || task >= c->T) return fail("bad task");

@@ -68,6 +68,14 @@ int oracle_update_task_models(oracle_ctx* ctx);
 int oracle_compute_control_torques(oracle_ctx* ctx, double* tau, int with_compensation);
 int oracle_tick(oracle_ctx* ctx, double* tau);
 
+/* TemplateTask virtuals on one task (TemplateTask.h:42-88): N_prec [49][B] or NULL = identity; tau_prec [7][B] or
+ * NULL = the no-argument computeTorques(); like the reference, computeTorques uses the model cached by the last
+ * updateTaskModel and the robot model of the current state */
+int oracle_task_update_model(oracle_ctx* ctx, int task, const double* N_prec);
+int oracle_task_compute_torques(oracle_ctx* ctx, int task, const double* tau_prec, double* tau);
+int oracle_task_reinitialize(oracle_ctx* ctx, int task);
+int oracle_task_get_nullspaces(oracle_ctx* ctx, int task, double* N, double* N_prec, double* N_total);
+
 int oracle_get_task_nullspace(oracle_ctx* ctx, int task, double* N_total);
 int oracle_get_task_torques(oracle_ctx* ctx, int task, double* tau_task);
 int oracle_get_mft_singularity(oracle_ctx* ctx, int task, double* sigma, double* alpha,

@@ -116,6 +116,7 @@ class TaskConfig(C.Structure):
         ("otg_max_linear_acceleration", _d),
         ("otg_max_angular_velocity", _d),
         ("otg_max_angular_acceleration", _d),
+        ("unsafe_motion_gains", _i),
     ]
 
 
@@ -188,8 +189,17 @@ EXPORTS = [
     "sai2b_compute_control_torques",
     "sai2b_compute_control_torques_ex",
     "sai2b_tick",
+    "sai2b_task_update_model",
+    "sai2b_task_compute_torques",
+    "sai2b_task_reinitialize",
+    "sai2b_task_get_nullspaces",
+    "sai2b_get_mft_singularity_state",
+    "sai2b_get_mft_velocity",
+    "sai2b_get_mft_sigma",
+    "sai2b_set_mft_type1_posture",
     "sai2b_synchronize",
     "sai2b_stream",
+    "sai2b_set_caller_stream",
     "sai2b_device_buffer",
     "sai2b_enable_introspection",
     "sai2b_get_task_nullspace",
@@ -263,9 +273,18 @@ def load_library():
     lib.sai2b_compute_control_torques.argtypes = [vp, vp, _i]
     lib.sai2b_compute_control_torques_ex.argtypes = [vp, vp, _i, _i]
     lib.sai2b_tick.argtypes = [vp, vp, _i]
+    lib.sai2b_task_update_model.argtypes = [vp, _i, vp, _i]
+    lib.sai2b_task_compute_torques.argtypes = [vp, _i, vp, vp, _i]
+    lib.sai2b_task_reinitialize.argtypes = [vp, _i]
+    lib.sai2b_task_get_nullspaces.argtypes = [vp, _i, vp, vp, vp]
+    lib.sai2b_get_mft_singularity_state.argtypes = [vp, _i, vp, vp, vp]
+    lib.sai2b_get_mft_velocity.argtypes = [vp, _i, vp, vp]
+    lib.sai2b_get_mft_sigma.argtypes = [vp, _i, vp, vp, vp, vp]
+    lib.sai2b_set_mft_type1_posture.argtypes = [vp, _i, vp, _i]
     lib.sai2b_synchronize.argtypes = [vp]
     lib.sai2b_stream.argtypes = [vp]
     lib.sai2b_stream.restype = vp
+    lib.sai2b_set_caller_stream.argtypes = [vp, vp]
     lib.sai2b_device_buffer.argtypes = [vp, _i, _i]
     lib.sai2b_device_buffer.restype = vp
     lib.sai2b_enable_introspection.argtypes = [vp, _i]

@@ -126,6 +126,7 @@ class Controller:
             if "hip" in msg.lower():
                 raise RuntimeError(msg)
             raise ValueError(msg)
+        self._caller_stream = 0  # the legacy default stream
         if introspection:
             self.enable_introspection(True)
 
@@ -151,6 +152,13 @@ class Controller:
         if hasattr(a, "data_ptr"):  # torch tensor
             if not a.is_cuda or not a.is_contiguous() or tuple(a.shape) != (rows, self.B) or str(a.dtype) != "torch.float64":
                 raise ValueError(f"expected a contiguous float64 CUDA tensor of shape ({rows}, {self.B})")
+            # the tensor was (or is being) produced on torch's current stream: sai2b.h "stream contract"
+            import torch
+
+            s = torch.cuda.current_stream(a.device).cuda_stream
+            if s != self._caller_stream:
+                self._rc(self.lib.sai2b_set_caller_stream(self.h, C.c_void_p(s)))
+                self._caller_stream = s
             return C.c_void_p(a.data_ptr()), a
         arr = np.ascontiguousarray(a, dtype=np.float64)
         if arr.shape != (rows, self.B):
@@ -226,6 +234,53 @@ class Controller:
             raise ValueError("out must be a C-contiguous float64 array")
         self._rc(call(p, self._dev(out)))
         return out
+
+    # -- task-level plugin interface (TemplateTask.h:42-88): one task driven on its own
+    def task_update_model(self, task, N_prec=None):
+        """TemplateTask::updateTaskModel(N_prec); N_prec [n*n][B] (numpy or torch CUDA), None = identity"""
+        p, _ = self._in(N_prec, DOF * DOF)
+        self._rc(self.lib.sai2b_task_update_model(self.h, task, p, self._dev(N_prec)))
+
+    def task_compute_torques(self, task, tau_prec=None, out=None):
+        """TemplateTask::computeTorques() / computeTorques(tau_prec): the task's own torques [n][B]"""
+        p, _ = self._in(tau_prec, DOF)
+        if out is None:
+            out = np.empty((DOF, self.B))
+        po, keep = self._in(out, DOF)
+        if tau_prec is not None and self._dev(tau_prec) != self._dev(out):
+            raise ValueError("tau_prec and out must both be host arrays or both device tensors")
+        self._rc(self.lib.sai2b_task_compute_torques(self.h, task, p, po, self._dev(out)))
+        return out
+
+    def task_reinitialize(self, task):
+        self._rc(self.lib.sai2b_task_reinitialize(self.h, task))
+
+    def task_nullspaces(self, task):
+        """(N, N_prec, N * N_prec) of the task's last model update, [n*n][B] each"""
+        out = [np.empty((DOF * DOF, self.B)) for _ in range(3)]
+        self._rc(self.lib.sai2b_task_get_nullspaces(self.h, task, *[C.c_void_p(x.ctypes.data) for x in out]))
+        return tuple(out)
+
+    def get_mft_velocity(self, task):
+        v, w = np.empty((3, self.B)), np.empty((3, self.B))
+        self._rc(self.lib.sai2b_get_mft_velocity(self.h, task, C.c_void_p(v.ctypes.data), C.c_void_p(w.ctypes.data)))
+        return v, w
+
+    def get_mft_sigma(self, task):
+        """sigmaForce, sigmaPosition, sigmaMoment, sigmaOrientation: [9][B] row-major each"""
+        out = [np.empty((9, self.B)) for _ in range(4)]
+        self._rc(self.lib.sai2b_get_mft_sigma(self.h, task, *[C.c_void_p(x.ctypes.data) for x in out]))
+        return tuple(out)
+
+    def set_mft_type1_posture(self, task, q_des):
+        p, _ = self._in(q_des, DOF)
+        self._rc(self.lib.sai2b_set_mft_type1_posture(self.h, task, p, self._dev(q_des)))
+
+    def get_singularity_types_count(self, task):
+        """per robot: singular directions found by the last model update (SingularityHandler.h:211), no introspection needed"""
+        n = np.empty(self.B, dtype=np.int32)
+        self._rc(self.lib.sai2b_get_mft_singularity_state(self.h, task, C.c_void_p(n.ctypes.data), None, None))
+        return n
 
     def synchronize(self):
         self._rc(self.lib.sai2b_synchronize(self.h))
@@ -365,6 +420,7 @@ class BatchedRobotModel:
         self._q = np.zeros((DOF, self.batch))
         self._dq = np.zeros((DOF, self.batch))
         self._controller = None
+        self._standalone = []  # tasks driven on their own (TemplateTask-level calls): each has its 1-task context
 
     def dof(self):
         return DOF
@@ -390,14 +446,31 @@ class BatchedRobotModel:
     def _push(self):
         if self._controller is not None:
             self._controller._ctrl.set_state(self._q, self._dq)
+        for own in self._standalone:
+            own._ctrl.set_state(self._q, self._dq)
+
+
+class _StandaloneOwner:
+    """What a task that is not attached to a RobotController runs on: a context holding that one task
+    (sai2b.h "task-level plugin interface"). Created on the first call that needs the device."""
+
+    def __init__(self, robot, cfg, q_construction):
+        self._ctrl = Controller(robot.model, [cfg], robot.batch, robot.device)
+        # the reference constructs a task at the model's state of that moment (goals := current pose)
+        self._ctrl.set_state(q_construction, np.zeros_like(q_construction))
+        self._ctrl.reinitialize()
+        self._ctrl.set_state(robot.q(), robot.dq())
+        robot._standalone.append(self)
 
 
 class _TaskBase:
     def __init__(self, robot, cfg):
         self._robot = robot
         self._cfg = cfg
-        self._owner = None  # (RobotController, index) once attached
+        self._owner = None  # (RobotController, index) once attached; (_StandaloneOwner, 0) when driven on its own
         self._pending = {}
+        self._q_construction = np.array(robot.q(), dtype=np.float64, copy=True) if not hasattr(robot.q(), "data_ptr") else robot.q().cpu().numpy()
+        self._task_level = False  # the last model update came through updateTaskModel()
 
     # TemplateTask accessors (reference src/tasks/TemplateTask.h:95-115)
     def getTaskName(self):
@@ -434,13 +507,41 @@ class _TaskBase:
         self._pending[key] = value
         self._flush()
 
+    # ---- the TemplateTask virtuals (reference src/tasks/TemplateTask.h:42-88): a task driven on its own, the
+    # caller chaining the nullspaces as in examples/04-task_and_redundancy.cpp:141-150,188-189
+    def updateTaskModel(self, N_prec=None):
+        """N_prec [n*n][B] (row-major inside the component index), None = identity"""
+        rc, idx = self._require_owner()
+        rc._ctrl.task_update_model(idx, N_prec)
+        self._task_level = True
+
+    def computeTorques(self, tau_prec=None, out=None):
+        """computeTorques() / computeTorques(tau_prec): this task's torques [n][B]"""
+        rc, idx = self._require_owner()
+        return rc._ctrl.task_compute_torques(idx, tau_prec, out)
+
+    def reInitializeTask(self):
+        rc, idx = self._require_owner()
+        rc._ctrl.task_reinitialize(idx)
+
+    def getTaskNullspace(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.task_nullspaces(idx)[0]
+
+    def getPreviousTasksNullspace(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.task_nullspaces(idx)[1]
+
     def getTaskAndPreviousNullspace(self):
         rc, idx = self._require_owner()
-        return rc._ctrl.get_task_nullspace(idx)
+        if self._task_level:
+            return rc._ctrl.task_nullspaces(idx)[2]
+        return rc._ctrl.get_task_nullspace(idx)  # of the controller's last tick (introspection on)
 
     def _require_owner(self):
         if not self._owner:
-            raise ValueError("task is not attached to a RobotController")
+            self._owner = (_StandaloneOwner(self._robot, self._cfg, self._q_construction), 0)
+            self._flush()
         return self._owner
 
 
@@ -878,8 +979,70 @@ class MotionForceTask(_TaskBase):
         rc._ctrl.reset_integrators(idx, 2)
 
     def getUnitMassForce(self):
+        """MotionForceTask.h:266, of the last tick (introspection on)"""
         rc, idx = self._require_owner()
         return rc._ctrl.get_mft_task_forces(idx)[0]
+
+    def getCurrentLinearVelocity(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_velocity(idx)[0]
+
+    def getCurrentAngularVelocity(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_velocity(idx)[1]
+
+    def sigmaForce(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_sigma(idx)[0]
+
+    def sigmaPosition(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_sigma(idx)[1]
+
+    def sigmaMoment(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_sigma(idx)[2]
+
+    def sigmaOrientation(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_sigma(idx)[3]
+
+    def setPosControlGainsUnsafe(self, kp, kv, ki):
+        """MotionForceTask.h:283 (MotionForceTask.cpp: no sign check, per-axis values)"""
+        for n, v in zip(("kp_pos", "kv_pos", "ki_pos"), (kp, kv, ki)):
+            v = np.broadcast_to(np.asarray(v, dtype=float), (3,))
+            for i in range(3):
+                getattr(self._cfg, n)[i] = v[i]
+        self._sync_cfg()
+
+    def setOriControlGainsUnsafe(self, kp, kv, ki):
+        for n, v in zip(("kp_ori", "kv_ori", "ki_ori"), (kp, kv, ki)):
+            v = np.broadcast_to(np.asarray(v, dtype=float), (3,))
+            for i in range(3):
+                getattr(self._cfg, n)[i] = v[i]
+        self._sync_cfg()
+
+    def getForceControlGains(self):
+        return [(self._cfg.kp_force[0], self._cfg.kv_force[0], self._cfg.ki_force[0])]
+
+    def getMomentControlGains(self):
+        return [(self._cfg.kp_moment[0], self._cfg.kv_moment[0], self._cfg.ki_moment[0])]
+
+    def handleAllSingularitiesAsType1(self, flag=True):
+        """MotionForceTask.h:697"""
+        self._cfg.enforce_type_1_strategy = int(bool(flag))
+        self._sync_cfg()
+
+    def setType1Posture(self, q_des):
+        """MotionForceTask.h:706; q_des [n][B]"""
+        rc, idx = self._require_owner()
+        rc._ctrl.set_mft_type1_posture(idx, q_des)
+
+    def getForceMotionSingleAxis(self):
+        return np.array(self._cfg.force_axis[:])
+
+    def getMomentRotMotionSingleAxis(self):
+        return np.array(self._cfg.moment_axis[:])
 
     def getSigmaValues(self):
         rc, idx = self._require_owner()

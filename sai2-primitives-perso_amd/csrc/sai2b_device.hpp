@@ -721,7 +721,7 @@ DI void chain_append(Chain& ch, const real* rows, int nrows) {
 // (MotionForceTask.cpp:247-509, SingularityHandler.cpp:75-368).
 template <bool DEBUG>
 DI void mft_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B, int b, bool first, bool last,
-				 bool commit_sh, bool do_torque, real* Nprec, real* tau_total, Chain& chain) {
+				 bool commit_sh, bool do_torque, real* Nprec, real* tau_total, Chain& chain, real* Ntask_out = nullptr) {
 	Frames F;
 	fk(P.model, rc.q, F);
 	real x[3], R[9], Jw[6 * N], J[6 * N], Jp[6 * N];
@@ -1072,6 +1072,9 @@ DI void mft_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B
 			UNROLL for (int i = 0; i < 9; i++) st(t.dbg_pose, 3 + i, B, b, R[i]);
 		}
 	}
+	if (Ntask_out) {  // TemplateTask::getTaskNullspace (MotionForceTask.h:193), task-level calls only
+		UNROLL for (int i = 0; i < N * N; i++) st(Ntask_out, i, B, b, Ntask[i]);
+	}
 	// N_prec <- N N_prec (RobotController.cpp:58, MotionForceTask.h:207-209)
 	if (!last || DEBUG) {
 		if (first) {
@@ -1090,7 +1093,7 @@ DI void mft_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B
 // JointTask::updateTaskModel + computeTorques(tau_prec) for one robot (JointTask.cpp:218-356)
 template <bool DEBUG, bool RANGE_ONLY = false>
 DI void jt_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B, int b, bool first, bool last,
-				bool with_comp, bool do_torque, real* Nprec, real* tau_total, Chain& chain) {
+				bool with_comp, bool do_torque, real* Nprec, real* tau_total, Chain& chain, real* Ntask_out = nullptr) {
 	real Jp[N * N];
 	if (first) {
 		UNROLL for (int i = 0; i < N * N; i++) Jp[i] = t.S[i];
@@ -1241,6 +1244,9 @@ DI void jt_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B,
 	UNROLL for (int i = 0; i < N; i++) tau_total[i] += tau[i];
 	if (DEBUG && t.dbg_tau) {
 		UNROLL for (int i = 0; i < N; i++) st(t.dbg_tau, i, B, b, tau[i]);
+	}
+	if (Ntask_out) {  // TemplateTask::getTaskNullspace (JointTask.h:207), task-level calls only
+		UNROLL for (int i = 0; i < N * N; i++) st(Ntask_out, i, B, b, Ntask[i]);
 	}
 	if (!last || DEBUG) {
 		if (first) {

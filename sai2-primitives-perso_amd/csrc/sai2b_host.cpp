@@ -52,9 +52,21 @@ struct sai2b_ctx {
 	DevParams h_params;
 	DevParams* d_params = nullptr;
 	hipStream_t stream = nullptr;
+	// device-pointer arguments (on_device != 0) are produced / consumed on the caller's stream: ordered against the
+	// ctx stream with two events (sai2b_set_caller_stream; default: the legacy default stream)
+	hipStream_t caller_stream = nullptr;
+	hipEvent_t ev_in = nullptr, ev_out = nullptr;
 	double *q = nullptr, *dq = nullptr, *tau = nullptr;
-	double* status_buf = nullptr;  // [26][B] scratch of sai2b_get_mft_status
+	double* status_buf = nullptr;  // [68][B] scratch of sai2b_get_mft_status
 	double* sim_tau = nullptr;	// staging for host torques / bias read-back of the simulation harness
+	// task-level calls (TemplateTask.h:42-88): per task the caller's N_prec, the task's N and N * N_prec of the
+	// last sai2b_task_update_model, its torques and a staging copy of a host tau_prec; created on first use
+	struct TaskIO {
+		double *Nprec = nullptr, *N = nullptr, *Ntot = nullptr, *tau = nullptr, *tau_prec = nullptr;
+		bool nprec_given = false;  // false: identity (the value a task is constructed with)
+		bool model_fresh = false;  // sai2b_task_update_model ran for the current state
+		bool standalone = false;   // the task is being driven through the task-level calls
+	} tio[SAI2B_MAX_TASKS];
 	std::vector<void*> allocs;
 	long long launches = 0, ticks = 0;
 	std::string error;
@@ -335,10 +347,34 @@ extern "C" int sai2b_validate_tasks(const sai2b_task_config* tasks, int n_tasks,
 			if (t.moment_space_dimension < 0 || t.moment_space_dimension > 3)
 				err = "Moment space dimension should be between 0 and 3 in MotionForceTask::parametrizeMomentRotMotionSpaces\n";
 			if (t.sh_buffer_size < 1 || t.sh_buffer_size > SAI2B_SH_HISTORY) err = "singularity history size must be in [1, 200]";
-			for (int k = 0; err.empty() && k < 3; k++)
+			for (int k = 0; err.empty() && k < 3 && !t.unsafe_motion_gains; k++)
 				if (t.kp_pos[k] < 0 || t.kv_pos[k] < 0 || t.ki_pos[k] < 0 || t.kp_ori[k] < 0 || t.kv_ori[k] < 0 || t.ki_ori[k] < 0)
 					err = "all gains should be positive or zero in MotionForceTask::setPosControlGains\n";
+			// the single axis of a 1- or 2-dimensional force / moment space must be a direction (MotionForceTask.cpp:840-848,868-876)
+			auto axis_norm = [](const double* a) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); };
+			if (err.empty() && (t.force_space_dimension == 1 || t.force_space_dimension == 2) && !(axis_norm(t.force_axis) >= 1e-2))
+				err = "Force or motion axis should be a non singular vector in MotionForceTask::parametrizeForceMotionSpaces\n";
+			if (err.empty() && (t.moment_space_dimension == 1 || t.moment_space_dimension == 2) && !(axis_norm(t.moment_axis) >= 1e-2))
+				err = "Moment or rot motion axis should be a non singular vector in MotionForceTask::parametrizeMomentRotMotionSpaces\n";
+			// pos_range / ori_range are the ranks of the two diagonal blocks of the projection (MotionForceTask.cpp:146-152)
+			if (err.empty()) {
+				double w[6], V[36];
+				sym_eig(6, t.partial_projection, w, V);
+				int rank = 0;
+				bool projector = true;
+				for (int k = 0; k < 6; k++) {
+					if (std::fabs(w[k] - 1.0) < 1e-9)
+						rank++;
+					else if (std::fabs(w[k]) > 1e-9)
+						projector = false;
+				}
+				if (!projector || rank != t.pos_range + t.ori_range || t.pos_range < 0 || t.pos_range > 3 || t.ori_range < 0 || t.ori_range > 3 ||
+					rank == 0)
+					err = "MotionForceTask: partial_projection must be an orthogonal projector of rank pos_range + ori_range >= 1";
+			}
 		}
+		if (err.empty() && (t.dynamic_decoupling_type < SAI2B_FULL_DYNAMIC_DECOUPLING || t.dynamic_decoupling_type > SAI2B_IMPEDANCE))
+			err = "dynamic_decoupling_type must be FULL_DYNAMIC_DECOUPLING, BOUNDED_INERTIA_ESTIMATES or IMPEDANCE";
 		if (err.empty() && t.use_internal_otg) {
 			if (t.internal_otg_jerk_limited)
 				err = "the jerk-limited internal OTG (enableInternalOtgJerkLimited) is not implemented in this build";
@@ -379,6 +415,16 @@ extern "C" int sai2b_validate_tasks(const sai2b_task_config* tasks, int n_tasks,
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
+// the reference's setters keep the single axis normalised (MotionForceTask.cpp:840-848,868-876): C callers need not
+static void normalise_axes(sai2b_task_config& c) {
+	if (c.type != SAI2B_MOTION_FORCE_TASK) return;
+	for (double* a : {c.force_axis, c.moment_axis}) {
+		const double n = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+		if (n >= 1e-2)
+			for (int k = 0; k < 3; k++) a[k] /= n;
+	}
+}
+
 static void fill_dev_task(const sai2b_task_config& c, DevTask& d) {
 	d.type = c.type;
 	d.decoupling = c.dynamic_decoupling_type;
@@ -529,6 +575,8 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	if (device < 0 || device >= ndev) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_create: bad device index");
 	HIP_TRY(ctx, hipSetDevice(device));
 	HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+	HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming));
+	HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_out, hipEventDisableTiming));
 	ctx->B = batch, ctx->T = n_tasks, ctx->device = device;
 	ctx->model = *model;
 	const char* nf = std::getenv("SAI2B_NO_FAST_PATH");
@@ -561,8 +609,9 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	if ((rc = dev_alloc(ctx, &ctx->otg_list, SAI2B_MAX_TASKS * Bs))) return rc;
 	for (int t = 0; t < n_tasks; t++) {
 		ctx->cfg[t] = tasks[t];
+		normalise_axes(ctx->cfg[t]);
 		DevTask& d = hp.task[t];
-		fill_dev_task(tasks[t], d);
+		fill_dev_task(ctx->cfg[t], d);
 		if (tasks[t].type == SAI2B_MOTION_FORCE_TASK) {
 			if ((rc = dev_alloc(ctx, &d.goals, sai2b::MFT_GOAL_ROWS * Bs))) return rc;
 			if ((rc = dev_alloc(ctx, &d.sensed, 6 * Bs))) return rc;
@@ -585,7 +634,7 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	ctx->params_dirty = true;
 	if ((rc = upload_params(ctx))) return rc;
 	// the reference constructs tasks from the model's current state (q = 0 until set_state)
-	if (sai2b_launch_reinit(ctx->d_params, ctx->B, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "reinit launch failed");
+	if (sai2b_launch_reinit(ctx->d_params, ctx->B, -1, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "reinit launch failed");
 	if (sai2b_launch_otg_reinit(ctx->d_params, ctx->B, -1, 0, ctx->q, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG reinit launch failed");
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -618,6 +667,8 @@ extern "C" void sai2b_destroy(sai2b_ctx* ctx) {
 	if (!ctx) return;
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	for (void* p : ctx->allocs) (void)hipFree(p);
+	if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
+	if (ctx->ev_out) (void)hipEventDestroy(ctx->ev_out);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -664,9 +715,10 @@ extern "C" int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_ta
 		reparam = (lin ? 1 | 4 : 0) | (ang ? 2 | 8 : 0) | (cl_f ? 4 : 0) | (cl_m ? 8 : 0);
 	}
 	ctx->cfg[task] = *cfg;
+	normalise_axes(ctx->cfg[task]);
 	DevTask& d = ctx->h_params.task[task];
 	DevTask keep = d;
-	fill_dev_task(*cfg, d);
+	fill_dev_task(ctx->cfg[task], d);
 	d.popc_f = keep.popc_f, d.popc_i = keep.popc_i, d.popc_q = keep.popc_q;
 	// enable(): just switches on; disable(): also reinitialises (POPCExplicitForceControl.cpp:24-28).
 	// Buffers must exist before the first enabled tick.
@@ -713,11 +765,30 @@ extern "C" int sai2b_enable_gravity_compensation(sai2b_ctx* ctx, int enable) {
 	return SAI2B_OK;
 }
 
+// Ordering of device-pointer arguments against the caller's stream. before_read: work the caller enqueued on its
+// stream so far (the producer of the argument) completes before what the ctx stream does next; after_read: what
+// the ctx stream has been given so far (the read of the argument, or the write of a device result) completes
+// before anything the caller enqueues on its stream afterwards — so the caller may overwrite an input, or
+// consume a result, right after the call returns without synchronising.
+static int caller_before_read(sai2b_ctx* ctx) {
+	HIP_TRY(ctx, hipEventRecord(ctx->ev_in, ctx->caller_stream));
+	HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_in, 0));
+	return SAI2B_OK;
+}
+static int caller_after_read(sai2b_ctx* ctx) {
+	HIP_TRY(ctx, hipEventRecord(ctx->ev_out, ctx->stream));
+	HIP_TRY(ctx, hipStreamWaitEvent(ctx->caller_stream, ctx->ev_out, 0));
+	return SAI2B_OK;
+}
+
 static int copy_rows(sai2b_ctx* ctx, double* dst, const double* src, size_t rows, int on_device) {
 	if (!src) return SAI2B_OK;
+	int rc;
+	if (on_device && (rc = caller_before_read(ctx))) return rc;
 	HIP_TRY(ctx, hipMemcpyAsync(dst, src, rows * (size_t)ctx->B * sizeof(double),
 								on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
-	if (!on_device) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // pageable host memory may be reused by the caller
+	if (on_device) return caller_after_read(ctx);
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // pageable host memory may be reused by the caller
 	return SAI2B_OK;
 }
 
@@ -737,6 +808,7 @@ extern "C" int sai2b_set_state(sai2b_ctx* ctx, const double* q, const double* dq
 	if ((rc = copy_rows(ctx, ctx->q, q, N, on_device))) return rc;
 	if ((rc = copy_rows(ctx, ctx->dq, dq, N, on_device))) return rc;
 	ctx->models_fresh = false;
+	for (int t = 0; t < ctx->T; t++) ctx->tio[t].model_fresh = false;
 	return SAI2B_OK;
 }
 
@@ -799,7 +871,7 @@ extern "C" int sai2b_reinitialize(sai2b_ctx* ctx) {
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	int rc = upload_params(ctx);
 	if (rc) return rc;
-	if (sai2b_launch_reinit(ctx->d_params, ctx->B, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "reinit launch failed");
+	if (sai2b_launch_reinit(ctx->d_params, ctx->B, -1, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "reinit launch failed");
 	if (sai2b_launch_otg_reinit(ctx->d_params, ctx->B, -1, 0, ctx->q, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG reinit launch failed");
 	ctx->goals_dirty = ~0u;
@@ -839,6 +911,8 @@ static unsigned refresh_otg_gating(sai2b_ctx* ctx) {
 		int gated = 0;
 		if (d.type == SAI2B_JOINT_TASK) {
 			gated = (d.otg_on && t > 0 && !(d.k0 == N && dof_above < N)) ? 1 : 0;
+			// driven on its own behind a caller-supplied N_prec: nothing is known about its range
+			if (ctx->tio[t].standalone) gated = (d.otg_on && ctx->tio[t].nprec_given) ? 1 : 0;
 			dof_above += d.k0;
 		} else {
 			dof_above += d.rank;
@@ -852,8 +926,11 @@ static unsigned refresh_otg_gating(sai2b_ctx* ctx) {
 	return mask;
 }
 
+static int fetch_rows(sai2b_ctx* ctx, const double* src, size_t row0, size_t rows, double* dst);
+
 static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torque) {
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	for (int t = 0; t < ctx->T; t++) ctx->tio[t].standalone = ctx->tio[t].model_fresh = false;
 	const unsigned gated = refresh_otg_gating(ctx);
 	int rc = upload_params(ctx);
 	if (rc) return rc;
@@ -868,7 +945,7 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 		// (a gated task keeps reading its goals: a robot skipped while they changed must see them later)
 		const int clean_mask = ctx->goals_exposed ? 0 : (int)(~ctx->goals_dirty & ~gated & ((1u << SAI2B_MAX_TASKS) - 1u));
 		ctx->goals_dirty = 0;
-		if (sai2b_launch_otg(ctx->d_params, ctx->B, ctx->otg_counts, ctx->otg_list, ctx->otg_parity, clean_mask, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG launch failed");
+		if (sai2b_launch_otg(ctx->d_params, ctx->B, ctx->otg_counts, ctx->otg_list, ctx->otg_parity, clean_mask, ~0, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG launch failed");
 		ctx->otg_parity ^= 1;
 		ctx->launches += 2;
 	}
@@ -921,12 +998,128 @@ extern "C" int sai2b_tick(sai2b_ctx* ctx, double* tau, int on_device) {
 	return fetch_tau(ctx, tau, on_device);
 }
 
+// ------------------------------------------------------------------------------------------------
+// task-level plugin interface (TemplateTask.h:42-88): one task driven on its own
+// ------------------------------------------------------------------------------------------------
+static int task_io(sai2b_ctx* ctx, int task, const char* fn) {
+	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	if (task < 0 || task >= ctx->T) return set_error(ctx, SAI2B_INVALID_ARGUMENT, std::string(fn) + ": bad task index");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	sai2b_ctx::TaskIO& io = ctx->tio[task];
+	if (!io.N) {
+		const size_t B = ctx->B;
+		int rc;
+		if ((rc = dev_alloc(ctx, &io.Nprec, N * N * B))) return rc;
+		if ((rc = dev_alloc(ctx, &io.N, N * N * B))) return rc;
+		if ((rc = dev_alloc(ctx, &io.Ntot, N * N * B))) return rc;
+		if ((rc = dev_alloc(ctx, &io.tau, N * B))) return rc;
+		if ((rc = dev_alloc(ctx, &io.tau_prec, N * B))) return rc;
+	}
+	io.standalone = true;
+	return SAI2B_OK;
+}
+
+extern "C" int sai2b_task_update_model(sai2b_ctx* ctx, int task, const double* N_prec, int on_device) {
+	int rc = task_io(ctx, task, "sai2b_task_update_model");
+	if (rc) return rc;
+	sai2b_ctx::TaskIO& io = ctx->tio[task];
+	io.nprec_given = N_prec != nullptr;
+	if ((rc = copy_rows(ctx, io.Nprec, N_prec, N * N, on_device))) return rc;
+	refresh_otg_gating(ctx);
+	if ((rc = upload_params(ctx))) return rc;
+	if (sai2b_launch_task(ctx->d_params, ctx->B, task, io.nprec_given ? io.Nprec : nullptr, nullptr, nullptr, io.N, io.Ntot,
+						  /*commit_sh=*/1, /*do_torque=*/0, ctx->stream))
+		return set_error(ctx, SAI2B_RUNTIME_ERROR, "task model launch failed");
+	ctx->launches++;
+	io.model_fresh = true;
+	return SAI2B_OK;
+}
+
+extern "C" int sai2b_task_compute_torques(sai2b_ctx* ctx, int task, const double* tau_prec, double* tau, int on_device) {
+	int rc = task_io(ctx, task, "sai2b_task_compute_torques");
+	if (rc) return rc;
+	sai2b_ctx::TaskIO& io = ctx->tio[task];
+	const unsigned gated = refresh_otg_gating(ctx);
+	if ((rc = upload_params(ctx))) return rc;
+	const double* Np = io.nprec_given ? io.Nprec : nullptr;
+	const DevTask& d = ctx->h_params.task[task];
+	if (d.otg_on) {	 // the task's generator advances once per torque computation, before the law
+		if (((gated >> task) & 1) && !io.model_fresh) {
+			// is the JointTask's range empty for this robot now (JointTask.cpp:302-306)? models of the current state, nothing committed
+			if (sai2b_launch_task(ctx->d_params, ctx->B, task, Np, nullptr, nullptr, io.N, io.Ntot, 0, 0, ctx->stream))
+				return set_error(ctx, SAI2B_RUNTIME_ERROR, "task-range pass launch failed");
+			ctx->launches++;
+		}
+		const int clean = ctx->goals_exposed ? 0 : (int)(~ctx->goals_dirty & ~gated & (1u << task));
+		ctx->goals_dirty &= ~(1u << task);
+		if (sai2b_launch_otg(ctx->d_params, ctx->B, ctx->otg_counts, ctx->otg_list, ctx->otg_parity, clean, 1 << task, ctx->stream))
+			return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG launch failed");
+		ctx->otg_parity ^= 1;
+		ctx->launches += 2;
+	}
+	const double* tp = nullptr;
+	if (tau_prec && on_device) {
+		tp = tau_prec;
+		if ((rc = caller_before_read(ctx))) return rc;
+	} else if (tau_prec) {
+		if ((rc = copy_rows(ctx, io.tau_prec, tau_prec, N, 0))) return rc;
+		tp = io.tau_prec;
+	}
+	if (sai2b_launch_task(ctx->d_params, ctx->B, task, Np, tp, io.tau, io.N, io.Ntot, io.model_fresh ? 0 : 1, 1, ctx->stream))
+		return set_error(ctx, SAI2B_RUNTIME_ERROR, "task torque launch failed");
+	ctx->launches++;
+	ctx->ticks += ctx->B;
+	io.model_fresh = false;
+	ctx->q_is_pose = true;	// computeTorques caches the task's current pose
+	if (!tau) return SAI2B_OK;
+	HIP_TRY(ctx, hipMemcpyAsync(tau, io.tau, (size_t)N * ctx->B * sizeof(double), on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+								ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return SAI2B_OK;
+}
+
+extern "C" int sai2b_task_reinitialize(sai2b_ctx* ctx, int task) {
+	if (!ctx || task < 0 || task >= ctx->T) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_task_reinitialize: bad arguments");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	int rc = upload_params(ctx);
+	if (rc) return rc;
+	if (sai2b_launch_reinit(ctx->d_params, ctx->B, task, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "reinit launch failed");
+	if (sai2b_launch_otg_reinit(ctx->d_params, ctx->B, task, 0, ctx->q, ctx->stream))
+		return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG reinit launch failed");
+	ctx->goals_dirty |= 1u << task;
+	ctx->launches += 2;
+	ctx->models_fresh = false;
+	ctx->tio[task].model_fresh = false;
+	// reInitializeTask reads the pose of the current state; the other tasks keep theirs
+	if (ctx->T == 1) ctx->q_is_pose = true;
+	return SAI2B_OK;
+}
+
+extern "C" int sai2b_task_get_nullspaces(sai2b_ctx* ctx, int task, double* N_task, double* N_prec, double* N_total) {
+	int rc = task_io(ctx, task, "sai2b_task_get_nullspaces");
+	if (rc) return rc;
+	sai2b_ctx::TaskIO& io = ctx->tio[task];
+	if ((rc = fetch_rows(ctx, io.N, 0, N * N, N_task))) return rc;
+	if ((rc = fetch_rows(ctx, io.Ntot, 0, N * N, N_total))) return rc;
+	if (N_prec && !io.nprec_given) {  // identity, the value a task is constructed with (JointTask.cpp:62, MotionForceTask.cpp:138)
+		const size_t B = ctx->B;
+		for (int i = 0; i < N * N; i++) std::fill(N_prec + i * B, N_prec + (i + 1) * B, (i % (N + 1) == 0) ? 1.0 : 0.0);
+		return SAI2B_OK;
+	}
+	return fetch_rows(ctx, io.Nprec, 0, N * N, N_prec);
+}
+
 extern "C" int sai2b_synchronize(sai2b_ctx* ctx) {
 	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return SAI2B_OK;
 }
 extern "C" void* sai2b_stream(sai2b_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+extern "C" int sai2b_set_caller_stream(sai2b_ctx* ctx, void* stream) {
+	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	ctx->caller_stream = (hipStream_t)stream;
+	return SAI2B_OK;
+}
 
 extern "C" void* sai2b_device_buffer(sai2b_ctx* ctx, int which, int task) {
 	if (!ctx) return nullptr;
@@ -995,6 +1188,20 @@ extern "C" int sai2b_get_mft_singularity(sai2b_ctx* ctx, int task, double* sigma
 	if ((rc = fetch_dbg(ctx, alpha, s ? s + 6 * B : nullptr, 1))) return rc;
 	return fetch_dbg(ctx, ns_rank, s ? s + 7 * B : nullptr, 1);
 }
+// SingularityHandler members between ticks (SingularityHandler.h:211-215): how many singular directions the
+// last model update found (_singularity_types.size()) and the type-1 / type-2 counters of the history
+extern "C" int sai2b_get_mft_singularity_state(sai2b_ctx* ctx, int task, int* n_singular, int* type_1_count, int* type_2_count) {
+	int rc = mft_task_check(ctx, task, "sai2b_get_mft_singularity_state");
+	if (rc) return rc;
+	const int* IS = ctx->h_params.task[task].istate;
+	const size_t B = ctx->B;
+	int* dst[3] = {n_singular, type_1_count, type_2_count};
+	const int row[3] = {sai2b::IS_NTYPES, sai2b::IS_C1, sai2b::IS_C2};
+	for (int k = 0; k < 3; k++)
+		if (dst[k]) HIP_TRY(ctx, hipMemcpyAsync(dst[k], IS + row[k] * B, B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return SAI2B_OK;
+}
 extern "C" int sai2b_get_mft_task_forces(sai2b_ctx* ctx, int task, double* F_unit, double* F_force) {
 	int rc = mft_task_check(ctx, task, "sai2b_get_mft_task_forces");
 	if (rc) return rc;
@@ -1018,8 +1225,10 @@ extern "C" int sai2b_sim_step(sai2b_ctx* ctx, const double* tau, int on_device, 
 	int rc = upload_params(ctx);
 	if (rc) return rc;
 	const double* t = ctx->tau;	 // default: the torques of the last computeControlTorques
-	if (tau && on_device) {
+	const bool caller_tau = tau && on_device;
+	if (caller_tau) {
 		t = tau;
+		if ((rc = caller_before_read(ctx))) return rc;
 	} else if (tau) {
 		if (!ctx->sim_tau && (rc = dev_alloc(ctx, &ctx->sim_tau, (size_t)N * ctx->B))) return rc;
 		if ((rc = copy_rows(ctx, ctx->sim_tau, tau, N, 0))) return rc;
@@ -1032,6 +1241,8 @@ extern "C" int sai2b_sim_step(sai2b_ctx* ctx, const double* tau, int on_device, 
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "simulation launch failed");
 	ctx->launches++;
 	ctx->models_fresh = false;
+	for (int k = 0; k < ctx->T; k++) ctx->tio[k].model_fresh = false;
+	if (caller_tau) return caller_after_read(ctx);
 	return SAI2B_OK;
 }
 extern "C" int sai2b_get_state(sai2b_ctx* ctx, double* q, double* dq) {
@@ -1053,15 +1264,46 @@ extern "C" int sai2b_get_bias(sai2b_ctx* ctx, int with_gravity, double* bias) {
 	return fetch_rows(ctx, ctx->sim_tau, 0, N, bias);
 }
 
+static int run_status(sai2b_ctx* ctx, int task) {
+	int rc = upload_params(ctx);
+	if (rc) return rc;
+	if (!ctx->status_buf && (rc = dev_alloc(ctx, &ctx->status_buf, 68 * (size_t)ctx->B))) return rc;
+	if (sai2b_launch_mft_status(ctx->d_params, ctx->B, task, ctx->status_buf, ctx->stream))
+		return set_error(ctx, SAI2B_RUNTIME_ERROR, "status launch failed");
+	return SAI2B_OK;
+}
+extern "C" int sai2b_get_mft_velocity(sai2b_ctx* ctx, int task, double* linear_velocity, double* angular_velocity) {
+	int rc = mft_task_check(ctx, task, "sai2b_get_mft_velocity");
+	if (rc) return rc;
+	if ((rc = run_status(ctx, task))) return rc;
+	if ((rc = fetch_rows(ctx, ctx->status_buf, 26, 3, linear_velocity))) return rc;
+	return fetch_rows(ctx, ctx->status_buf, 29, 3, angular_velocity);
+}
+extern "C" int sai2b_get_mft_sigma(sai2b_ctx* ctx, int task, double* sigma_force, double* sigma_position, double* sigma_moment,
+								   double* sigma_orientation) {
+	int rc = mft_task_check(ctx, task, "sai2b_get_mft_sigma");
+	if (rc) return rc;
+	if ((rc = run_status(ctx, task))) return rc;
+	if ((rc = fetch_rows(ctx, ctx->status_buf, 32, 9, sigma_force))) return rc;
+	if ((rc = fetch_rows(ctx, ctx->status_buf, 41, 9, sigma_position))) return rc;
+	if ((rc = fetch_rows(ctx, ctx->status_buf, 50, 9, sigma_moment))) return rc;
+	return fetch_rows(ctx, ctx->status_buf, 59, 9, sigma_orientation);
+}
+// SingularityHandler::setType1Posture (SingularityHandler.h:140-142, via MotionForceTask.h:706): _q_prior := q_des.
+// Like the reference's member it holds until the handler next refreshes it (on entering a singular region, or
+// while type-2 classifications dominate: SingularityHandler.cpp:233-236).
+extern "C" int sai2b_set_mft_type1_posture(sai2b_ctx* ctx, int task, const double* q_des, int on_device) {
+	int rc = mft_task_check(ctx, task, "sai2b_set_mft_type1_posture");
+	if (rc) return rc;
+	if (!q_des) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_set_mft_type1_posture: null posture");
+	return copy_rows(ctx, ctx->h_params.task[task].state + 12 * (size_t)ctx->B, q_des, N, on_device);
+}
 extern "C" int sai2b_get_mft_status(sai2b_ctx* ctx, int task, double* pos, double* rot, double* sensed_force_world,
 									double* sensed_moment_world, double* pos_error, double* ori_error, double* pos_error_norm,
 									double* ori_error_norm) {
 	int rc = mft_task_check(ctx, task, "sai2b_get_mft_status");
 	if (rc) return rc;
-	if ((rc = upload_params(ctx))) return rc;
-	if (!ctx->status_buf && (rc = dev_alloc(ctx, &ctx->status_buf, 26 * (size_t)ctx->B))) return rc;
-	if (sai2b_launch_mft_status(ctx->d_params, ctx->B, task, ctx->status_buf, ctx->stream))
-		return set_error(ctx, SAI2B_RUNTIME_ERROR, "status launch failed");
+	if ((rc = run_status(ctx, task))) return rc;
 	const double* S = ctx->status_buf;
 	if ((rc = fetch_rows(ctx, S, 0, 3, pos))) return rc;
 	if ((rc = fetch_rows(ctx, S, 3, 9, rot))) return rc;

@@ -181,10 +181,67 @@ __global__ __launch_bounds__(64) void tick_fast_kernel(const DevParams* __restri
 	UNROLL for (int i = 0; i < N; i++) st(P.tau, i, B, b, tau[i] + g[i]);
 }
 
+// One task driven on its own, the reference's plugin interface (TemplateTask.h:42-88):
+//   updateTaskModel(N_prec)            -> do_torque = 0: the task's nullspace N and N * N_prec; the once-per-
+//                                         update singularity bookkeeping when commit_sh
+//   computeTorques() / (tau_prec)      -> do_torque = 1: the task's own torques (tau_prec == NULL: the
+//                                         no-argument form, no compensation of the previous tasks)
+// Nprec_in == NULL is the identity (a task constructed and never given one, JointTask.cpp:62,
+// MotionForceTask.cpp:138). Nothing is known about the tasks above, so the range decisions always take
+// the Jacobi SVD (the introspection instantiation of the task functions), and a JointTask applies the
+// compensation term also behind an identity N_prec, as JointTask::computeTorques(tau_prec) does
+// (JointTask.cpp:285-292). Used for examples 01 / 04 / 18-style manual hierarchies; the batched hot path is
+// the fused tick above.
+__global__ __launch_bounds__(64) void task_kernel(const DevParams* __restrict__ Pp, int task, const double* __restrict__ Nprec_in,
+													 const double* __restrict__ tau_prec, double* __restrict__ tau_out,
+													 double* __restrict__ N_out, double* __restrict__ Ntot_out, int commit_sh,
+													 int do_torque) {
+	const DevParams& P = *Pp;
+	const int B = P.B;
+	const int b = blockIdx.x * 64 + threadIdx.x;
+	if (b >= B) return;
+	RobotCtx rc;
+	UNROLL for (int i = 0; i < N; i++) {
+		rc.q[i] = ld(P.q, i, B, b);
+		rc.dq[i] = ld(P.dq, i, B, b);
+	}
+	const DevTask& tk = P.task[task];
+	{
+		Frames F;
+		fk(P.model, rc.q, F);
+		real M[N * N];
+		mass_matrix(P.model, F, M);
+		spd_inverse<N>(M, rc.Minv);
+		if (tk.decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES) {
+			UNROLL for (int i = 0; i < N; i++) M[i * N + i] = fmax(M[i * N + i], tk.bie_threshold);
+			spd_inverse<N>(M, rc.MinvB);
+		} else {
+			UNROLL for (int i = 0; i < N * N; i++) rc.MinvB[i] = rc.Minv[i];
+		}
+	}
+	real Nprec[N * N], tau[N], tp[N];
+	UNROLL for (int i = 0; i < N * N; i++) Nprec[i] = Nprec_in ? ld(Nprec_in, i, B, b) : ((i % (N + 1) == 0) ? 1.0 : 0.0);
+	UNROLL for (int i = 0; i < N; i++) tau[i] = tp[i] = tau_prec ? ld(tau_prec, i, B, b) : 0.0;
+	Chain chain;
+	chain.ok = false;
+	chain.wrows = 0;
+	UNROLL for (int i = 0; i < N * N; i++) chain.W[i] = 0;
+	if (tk.type == SAI2B_MOTION_FORCE_TASK)
+		mft_task<true>(P, tk, rc, B, b, false, false, commit_sh != 0, do_torque != 0, Nprec, tau, chain, N_out);
+	else
+		jt_task<true>(P, tk, rc, B, b, false, false, tau_prec != nullptr, do_torque != 0, Nprec, tau, chain, N_out);
+	if (Ntot_out) {
+		UNROLL for (int i = 0; i < N * N; i++) st(Ntot_out, i, B, b, Nprec[i]);
+	}
+	if (do_torque && tau_out) {
+		UNROLL for (int i = 0; i < N; i++) st(tau_out, i, B, b, tau[i] - tp[i]);
+	}
+}
+
 // RobotController::reinitializeTasks (RobotController.cpp:76-80): MotionForceTask::reInitializeTask
 // (MotionForceTask.cpp:204-245), SingularityHandler ctor state (SingularityHandler.cpp:53-63),
 // JointTask::reInitializeTask (JointTask.cpp:91-107)
-__global__ __launch_bounds__(64) void reinit_kernel(const DevParams* __restrict__ Pp) {
+__global__ __launch_bounds__(64) void reinit_kernel(const DevParams* __restrict__ Pp, int only_task) {
 	const DevParams& P = *Pp;
 	const int B = P.B;
 	const int b = blockIdx.x * 64 + threadIdx.x;
@@ -196,6 +253,7 @@ __global__ __launch_bounds__(64) void reinit_kernel(const DevParams* __restrict_
 #pragma unroll 1
 	for (int t = 0; t < P.n_tasks; t++) {
 		const DevTask& tk = P.task[t];
+		if (only_task >= 0 && t != only_task) continue;	 // TemplateTask::reInitializeTask of one task
 		if (tk.type == SAI2B_MOTION_FORCE_TASK) {
 			real x[3], R[9];
 			frame_pose(tk, F, x, R);
@@ -280,8 +338,15 @@ extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, i
 	return (int)hipGetLastError();
 }
 
-extern "C" int sai2b_launch_reinit(const sai2b::DevParams* d_params, int B, hipStream_t stream) {
+extern "C" int sai2b_launch_reinit(const sai2b::DevParams* d_params, int B, int only_task, hipStream_t stream) {
 	const int blocks = (B + 63) / 64;
-	hipLaunchKernelGGL(sai2b::reinit_kernel, dim3(blocks), dim3(64), 0, stream, d_params);
+	hipLaunchKernelGGL(sai2b::reinit_kernel, dim3(blocks), dim3(64), 0, stream, d_params, only_task);
+	return (int)hipGetLastError();
+}
+
+extern "C" int sai2b_launch_task(const sai2b::DevParams* d_params, int B, int task, const double* Nprec_in, const double* tau_prec,
+								 double* tau_out, double* N_out, double* Ntot_out, int commit_sh, int do_torque, hipStream_t stream) {
+	hipLaunchKernelGGL(sai2b::task_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, d_params, task, Nprec_in, tau_prec, tau_out, N_out,
+					   Ntot_out, commit_sh, do_torque);
 	return (int)hipGetLastError();
 }

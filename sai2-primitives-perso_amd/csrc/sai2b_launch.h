@@ -7,15 +7,22 @@
 extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int commit_sh,
 								 int with_comp, int do_torque, int* fb_counts, int* fb_list, int parity, hipStream_t stream);
 extern "C" int sai2b_launch_range_pass(const sai2b::DevParams* d_params, int B, int debug, int with_comp, hipStream_t stream);
-extern "C" int sai2b_launch_reinit(const sai2b::DevParams* d_params, int B, hipStream_t stream);
+// only_task < 0: every task (RobotController::reinitializeTasks); else TemplateTask::reInitializeTask of that one
+extern "C" int sai2b_launch_reinit(const sai2b::DevParams* d_params, int B, int only_task, hipStream_t stream);
+// one task on its own (TemplateTask.h:42-88): model update (do_torque = 0) or the task's torques (do_torque = 1) under
+// a caller-supplied N_prec ([49][B], NULL = identity) and tau_prec ([7][B], NULL = the no-argument computeTorques());
+// N_out / Ntot_out [49][B]: the task's nullspace and N * N_prec; tau_out [7][B]
+extern "C" int sai2b_launch_task(const sai2b::DevParams* d_params, int B, int task, const double* Nprec_in, const double* tau_prec,
+								 double* tau_out, double* N_out, double* Ntot_out, int commit_sh, int do_torque, hipStream_t stream);
 // one kernel of a (fast) tick on its own, for per-kernel timing: part 0 = first kernel, part 1 = the
 // generic kernel over the work list of the SVD-free one. fb_counts: 2 ints, zero before the first
 // launch; fb_list: B ints; parity alternates 0/1 between consecutive launches of the SVD-free kernel
 extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int part,
 									  int* fb_counts, int* fb_list, int parity, hipStream_t stream);
 // internal OTG (sai2b_otg.hip): one update of every enabled generator; (re)initialisation (modes in the kernel's comment)
+// task_mask bit t: advance task t's generator (all enabled ones: ~0)
 extern "C" int sai2b_launch_otg(const sai2b::DevParams* d_params, int B, int* counts, int* list, int parity, int clean_mask,
-								hipStream_t stream);
+								int task_mask, hipStream_t stream);
 // q_pose: [7][B] joint positions the tasks' cached poses correspond to (read in mode 1 only)
 extern "C" int sai2b_launch_otg_reinit(const sai2b::DevParams* d_params, int B, int only_task, int mode, const double* q_pose,
 									   hipStream_t stream);
@@ -25,5 +32,5 @@ extern "C" int sai2b_launch_mft_reparam(const sai2b::DevParams* d_params, int B,
 // simulation harness (sai2b_sim.hip): one control period of rigid-body dynamics, state updated in place
 extern "C" int sai2b_launch_sim(const sai2b::DevParams* d_params, int B, const double* tau, double dt, int substeps,
 								int with_gravity, double* dbg_bias, double* q_keep, hipStream_t stream);
-// observers of a MotionForceTask between ticks: out [26][B] (rows in sai2b_sim.hip: mft_status_kernel)
+// observers of a MotionForceTask between ticks: out [68][B] (rows in sai2b_sim.hip: mft_status_kernel)
 extern "C" int sai2b_launch_mft_status(const sai2b::DevParams* d_params, int B, int task, double* out, hipStream_t stream);

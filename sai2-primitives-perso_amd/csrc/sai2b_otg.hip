@@ -397,7 +397,7 @@ DI void plan_group(const DevTask& t, bool cart, int n, int B, int b) {
 // that need the planner are appended to the task's work list (one atomic per wavefront, lanes of a
 // wavefront stay adjacent and ordered, so the plan kernel's accesses coalesce in runs).
 __global__ __launch_bounds__(64) void otg_kernel(const DevParams* __restrict__ Pp, int* __restrict__ counts,
-												 int* __restrict__ list, int parity, int clean_mask) {
+												 int* __restrict__ list, int parity, int clean_mask, int task_mask) {
 	const DevParams& P = *Pp;
 	const int B = P.B;
 	const int b = blockIdx.x * 64 + threadIdx.x;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(64) void otg_kernel(const DevParams* __restrict__ P
 #pragma unroll 1
 	for (int t = 0; t < P.n_tasks; t++) {
 		const DevTask& tk = P.task[t];
-		if (!tk.otg_on) continue;
+		if (!tk.otg_on || !((task_mask >> t) & 1)) continue;
 		const bool cart = tk.type == SAI2B_MOTION_FORCE_TASK;
 		int cls = IDLE;
 		// a JointTask with an empty range returns before it touches its generator (JointTask.cpp:302-306)
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(64) void otg_kernel(const DevParams* __restrict__ P
 // The robots otg_kernel left over (goal changed / input differs), compacted: group i (8 lanes, one DoF
 // per lane) of the grid takes entry i of the task's list and does the robot's full update.
 __global__ __launch_bounds__(64) void otg_plan_kernel(const DevParams* __restrict__ Pp, int* __restrict__ counts,
-													  const int* __restrict__ list, int parity) {
+													  const int* __restrict__ list, int parity, int task_mask) {
 	const DevParams& P = *Pp;
 	const int B = P.B;
 	if (blockIdx.x == 0 && threadIdx.x < SAI2B_MAX_TASKS) ((gint*)counts)[(1 - parity) * SAI2B_MAX_TASKS + threadIdx.x] = 0;  // next tick's counters
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64) void otg_plan_kernel(const DevParams* __restric
 #pragma unroll 1
 	for (int t = 0; t < P.n_tasks; t++) {
 		const DevTask& tk = P.task[t];
-		if (!tk.otg_on) continue;
+		if (!tk.otg_on || !((task_mask >> t) & 1)) continue;
 		const int cnt = ((const gint*)counts)[parity * SAI2B_MAX_TASKS + t];
 		// grid-stride over the list: the grid is sized for the machine, not for the worst-case list
 #pragma unroll 1
@@ -587,11 +587,11 @@ extern "C" int sai2b_launch_mft_reparam(const sai2b::DevParams* d_params, int B,
 // parity alternates 0/1 between consecutive calls
 // clean_mask bit t: the host has not written task t's goals / OTG settings since the previous call
 extern "C" int sai2b_launch_otg(const sai2b::DevParams* d_params, int B, int* counts, int* list, int parity, int clean_mask,
-								hipStream_t stream) {
+								int task_mask, hipStream_t stream) {
 	const dim3 grid((B + 63) / 64), block(64);
-	hipLaunchKernelGGL(sai2b::otg_kernel, grid, block, 0, stream, d_params, counts, list, parity, clean_mask);
+	hipLaunchKernelGGL(sai2b::otg_kernel, grid, block, 0, stream, d_params, counts, list, parity, clean_mask, task_mask);
 	const int plan_blocks = (B + 7) / 8 < 2048 ? (B + 7) / 8 : 2048;
-	hipLaunchKernelGGL(sai2b::otg_plan_kernel, dim3(plan_blocks), block, 0, stream, d_params, counts, (const int*)list, parity);
+	hipLaunchKernelGGL(sai2b::otg_plan_kernel, dim3(plan_blocks), block, 0, stream, d_params, counts, (const int*)list, parity, task_mask);
 	return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

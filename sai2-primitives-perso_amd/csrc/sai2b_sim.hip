@@ -136,12 +136,21 @@ __global__ __launch_bounds__(64) void mft_status_kernel(const DevParams* __restr
 	const int b = blockIdx.x * 64 + threadIdx.x;
 	if (b >= B) return;
 	const DevTask& t = P.task[task];
-	real q[N];
-	UNROLL for (int i = 0; i < N; i++) q[i] = ld(P.q, i, B, b);
+	real q[N], dq[N];
+	UNROLL for (int i = 0; i < N; i++) {
+		q[i] = ld(P.q, i, B, b);
+		dq[i] = ld(P.dq, i, B, b);
+	}
 	Frames F;
 	fk(P.model, q, F);
 	real x[3], R[9];
 	frame_pose(t, F, x, R);
+	{  // getCurrentLinearVelocity / getCurrentAngularVelocity (MotionForceTask.h:127-146, MotionForceTask.cpp:293-298)
+		real J[6 * N], v[6];
+		jacobian(t, F, x, J);
+		mv<6, N>(J, dq, v);
+		UNROLL for (int k = 0; k < 6; k++) st(out, 26 + k, B, b, v[k]);
+	}
 	real sf[9], sp[9], sm[9], so[9];
 	sigma_pair(t, 0, t.fdim, t.faxis, R, sf, sp);
 	sigma_pair(t, 1, t.mdim, t.maxis, R, sm, so);
@@ -171,7 +180,14 @@ __global__ __launch_bounds__(64) void mft_status_kernel(const DevParams* __restr
 		st(out, 18 + k, B, b, se[k]);
 		st(out, 21 + k, B, b, soe[k]);
 	}
-	UNROLL for (int k = 0; k < 9; k++) st(out, 3 + k, B, b, R[k]);
+	UNROLL for (int k = 0; k < 9; k++) {
+		st(out, 3 + k, B, b, R[k]);
+		// sigmaForce / sigmaPosition / sigmaMoment / sigmaOrientation (MotionForceTask.cpp:892-971)
+		st(out, 32 + k, B, b, sf[k]);
+		st(out, 41 + k, B, b, sp[k]);
+		st(out, 50 + k, B, b, sm[k]);
+		st(out, 59 + k, B, b, so[k]);
+	}
 	st(out, 24, B, b, sqrt(fmax(e[0] * se[0] + e[1] * se[1] + e[2] * se[2], 0.0)));
 	st(out, 25, B, b, sqrt(fmax(oe[0] * soe[0] + oe[1] * soe[1] + oe[2] * soe[2], 0.0)));
 }

@@ -2,6 +2,9 @@
 // uses the reference classes. Modes:
 //   facade_test validate        (no GPU) argument checks throw std::invalid_argument as the reference's
 //   facade_test tick <B> <in>   (GPU)    reads q,dq,goals (raw doubles) from <in>, prints torques
+//   facade_test example04 <B> <in> <ticks> / example01 <B> <in> <ticks>   (GPU) the reference's examples 04 and 01,
+//                               tasks driven through the TemplateTask virtuals with no RobotController
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -108,8 +111,134 @@ static int tick(int B, const char* path) {
 	return 0;
 }
 
+static Batch add(const Batch& a, const Batch& b) {
+	Batch c(a.size());
+	for (size_t i = 0; i < a.size(); i++) c[i] = a[i] + b[i];
+	return c;
+}
+
+// examples/04-task_and_redundancy/04-task_and_redundancy.cpp:101-206 call for call (no RobotController: the two
+// tasks are driven through the TemplateTask virtuals and the nullspace is chained by hand); the trajectory
+// and the cycle at which the joint task wakes up are compressed so that `ticks` periods cover them.
+// Prints the control torques of every period, then the final joint positions.
+static int example04(int B, const char* path, int ticks) {
+	std::ifstream f(path, std::ios::binary);
+	Batch q0(7 * (size_t)B), dq0(7 * (size_t)B, 0.0);
+	f.read((char*)q0.data(), q0.size() * sizeof(double));
+	auto robot = std::make_shared<BatchedRobotModel>(B);
+	robot->setQ(q0);
+	robot->setDq(dq0);
+	robot->updateModel();  // :104
+	const double pos_in_link[3] = {0.0, 0.0, 0.22};	 // "end-effector" (0, 0, 0.07) seen from link7: + 0.15 (:111-113)
+	auto motion_force_task = std::make_unique<MotionForceTask>(robot, 6, pos_in_link);	// :114-115
+	motion_force_task->disableInternalOtg();											// :117
+	const Batch initial_orientation = motion_force_task->getCurrentOrientation();		// :120
+	const Batch initial_position = motion_force_task->getCurrentPosition();				// :121
+	auto joint_task = std::make_unique<JointTask>(robot);								// :125 (default gains, OTG on)
+	const Batch initial_q = robot->q();													// :128
+	BatchedSimulation sim(*motion_force_task, 0.001, 1);
+	const int wake = ticks / 3;
+	for (int cycle = 0; cycle < ticks; cycle++) {
+		const double time = 0.001 * cycle;
+		robot->setQ(sim.getJointPositions());  // :139-141
+		robot->setDq(sim.getJointVelocities());
+		robot->updateModel();
+		motion_force_task->updateTaskModel();							 // :144-146 N_prec = identity
+		const Batch N_prec = motion_force_task->getTaskAndPreviousNullspace();	// :147
+		joint_task->updateTaskModel(N_prec);							 // :152
+		// orientation: oscillation around Y (:157-172), position: circle in the y-z plane (:175-185)
+		const double w_ori = 2 * M_PI * 0.2, amp = M_PI / 8, ang = amp * std::sin(w_ori * time);
+		const double c = std::cos(ang), s_ = std::sin(ang);
+		const double Rt[9] = {c, 0, -s_, 0, 1, 0, s_, 0, c};  // R^T for a rotation by ang about Y
+		Batch Rg(9 * (size_t)B), wg(3 * (size_t)B, 0.0), ag(3 * (size_t)B, 0.0), pg(3 * (size_t)B), vg(3 * (size_t)B), lg(3 * (size_t)B);
+		const double r = 0.05, wc = 2 * M_PI * 0.33;
+		const double dp[3] = {0.0, std::sin(wc * time), 1 - std::cos(wc * time)}, dv[3] = {0.0, std::cos(wc * time), std::sin(wc * time)},
+					 da[3] = {0.0, -std::sin(wc * time), std::cos(wc * time)};
+		for (int b = 0; b < B; b++) {
+			for (int i = 0; i < 3; i++)
+				for (int j = 0; j < 3; j++) {
+					double v = 0;
+					for (int k = 0; k < 3; k++) v += Rt[3 * i + k] * initial_orientation[(size_t)(3 * k + j) * B + b];
+					Rg[(size_t)(3 * i + j) * B + b] = v;
+				}
+			wg[(size_t)1 * B + b] = amp * w_ori * std::cos(w_ori * time);
+			ag[(size_t)1 * B + b] = amp * w_ori * w_ori * -std::sin(w_ori * time);
+			for (int i = 0; i < 3; i++) {
+				pg[(size_t)i * B + b] = initial_position[(size_t)i * B + b] + r * dp[i];
+				vg[(size_t)i * B + b] = r * wc * dv[i];
+				lg[(size_t)i * B + b] = r * wc * wc * da[i];
+			}
+		}
+		motion_force_task->setGoalOrientation(Rg);
+		motion_force_task->setGoalAngularVelocity(wg);
+		motion_force_task->setGoalAngularAcceleration(ag);
+		motion_force_task->setGoalPosition(pg);
+		motion_force_task->setGoalLinearVelocity(vg);
+		motion_force_task->setGoalLinearAcceleration(lg);
+		Batch motion_force_task_torques = motion_force_task->computeTorques();	// :188
+		Batch joint_task_torques = joint_task->computeTorques();				// :189
+		if (cycle < wake) std::fill(joint_task_torques.begin(), joint_task_torques.end(), 0.0);	 // :193-195
+		if (cycle == wake) {													// :196-201
+			joint_task->reInitializeTask();
+			Batch goal_joint_pos = initial_q;
+			for (int b = 0; b < B; b++) goal_joint_pos[b] += 1.5;
+			joint_task->setGoalPosition(goal_joint_pos);
+		}
+		const Batch control_torques = add(motion_force_task_torques, joint_task_torques);  // :206
+		std::fwrite(control_torques.data(), sizeof(double), control_torques.size(), stdout);
+		sim.setJointTorques(control_torques);
+		sim.integrate();
+	}
+	const Batch q1 = sim.getJointPositions();
+	std::fwrite(q1.data(), sizeof(double), q1.size(), stdout);
+	return 0;
+}
+
+// examples/01-joint_control/01-joint_control.cpp:123-191 call for call (BASELINE config 1: one JointTask driven on
+// its own), the schedule of goal steps / gain changes / velocity saturation compressed into `ticks` periods.
+static int example01(int B, const char* path, int ticks) {
+	std::ifstream f(path, std::ios::binary);
+	Batch q0(7 * (size_t)B), dq0(7 * (size_t)B, 0.0);
+	f.read((char*)q0.data(), q0.size() * sizeof(double));
+	auto robot = std::make_shared<BatchedRobotModel>(B);
+	robot->setQ(q0);
+	robot->setDq(dq0);
+	robot->updateModel();											// :126
+	auto joint_task = std::make_shared<JointTask>(robot);			// :131
+	joint_task->setGains(100, 20);									// :133
+	Batch goal_position = joint_task->getGoalPosition();			// :134
+	joint_task->disableInternalOtg();								// :136
+	BatchedSimulation sim(*joint_task, 0.001, 1);
+	Batch N_prec(49 * (size_t)B, 0.0);
+	for (int cycle = 0; cycle < ticks; cycle++) {
+		robot->setQ(sim.getJointPositions());  // :148-150
+		robot->setDq(sim.getJointVelocities());
+		robot->updateModel();
+		for (int i = 0; i < 7; i++)
+			for (int b = 0; b < B; b++) N_prec[(size_t)(8 * i) * B + b] = 1.0;	 // :153 setIdentity
+		joint_task->updateTaskModel(N_prec);									 // :154
+		if (cycle % 30 == 5)													 // :158-161
+			for (int b = 0; b < B; b++) goal_position[(size_t)2 * B + b] += 0.4, goal_position[(size_t)3 * B + b] -= 0.6;
+		if (cycle % 30 == 20)													 // :162-165
+			for (int b = 0; b < B; b++) goal_position[(size_t)2 * B + b] -= 0.4, goal_position[(size_t)3 * B + b] += 0.6;
+		joint_task->setGoalPosition(goal_position);								 // :166
+		if (cycle == 35) joint_task->setGains(100, 10);							 // :169-174
+		if (cycle == 45) joint_task->enableVelocitySaturation(M_PI / 4);		 // :176-181
+		if (cycle == 55) joint_task->setGains(100, 20);							 // :184-189
+		const Batch joint_task_torques = joint_task->computeTorques();			 // :191
+		std::fwrite(joint_task_torques.data(), sizeof(double), joint_task_torques.size(), stdout);
+		sim.setJointTorques(joint_task_torques);
+		sim.integrate();
+	}
+	const Batch q1 = sim.getJointPositions();
+	std::fwrite(q1.data(), sizeof(double), q1.size(), stdout);
+	return 0;
+}
+
 int main(int argc, char** argv) {
 	try {
+		if (argc >= 5 && std::strcmp(argv[1], "example04") == 0) return example04(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
+		if (argc >= 5 && std::strcmp(argv[1], "example01") == 0) return example01(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 2 && std::strcmp(argv[1], "validate") == 0) return validate();
 		if (argc >= 4 && std::strcmp(argv[1], "tick") == 0) return tick(std::atoi(argv[2]), argv[3]);
 	} catch (const std::exception& e) {

@@ -51,6 +51,10 @@ def lib():
     L.oracle_update_task_models.argtypes = [vp]
     L.oracle_compute_control_torques.argtypes = [vp, vp, i]
     L.oracle_tick.argtypes = [vp, vp]
+    L.oracle_task_update_model.argtypes = [vp, i, vp]
+    L.oracle_task_compute_torques.argtypes = [vp, i, vp, vp]
+    L.oracle_task_reinitialize.argtypes = [vp, i]
+    L.oracle_task_get_nullspaces.argtypes = [vp, i, vp, vp, vp]
     L.oracle_get_task_nullspace.argtypes = [vp, i, vp]
     L.oracle_get_task_torques.argtypes = [vp, i, vp]
     L.oracle_get_mft_singularity.argtypes = [vp, i, vp, vp, vp]
@@ -229,6 +233,25 @@ class Oracle:
         tau = np.empty((DOF, self.B)) if want_output else None
         self.L.oracle_tick(self.h, _ptr(tau))
         return tau
+
+    # task-level plugin interface (TemplateTask.h:42-88), same names as pkg.Controller
+    def task_update_model(self, task, N_prec=None):
+        N_prec = _arr(N_prec, (DOF * DOF, self.B))
+        assert self.L.oracle_task_update_model(self.h, task, _ptr(N_prec)) == 0
+
+    def task_compute_torques(self, task, tau_prec=None):
+        tau_prec = _arr(tau_prec, (DOF, self.B))
+        tau = np.empty((DOF, self.B))
+        assert self.L.oracle_task_compute_torques(self.h, task, _ptr(tau_prec), _ptr(tau)) == 0
+        return tau
+
+    def task_reinitialize(self, task):
+        assert self.L.oracle_task_reinitialize(self.h, task) == 0
+
+    def task_nullspaces(self, task):
+        out = [np.empty((DOF * DOF, self.B)) for _ in range(3)]
+        assert self.L.oracle_task_get_nullspaces(self.h, task, *[_ptr(x) for x in out]) == 0
+        return tuple(out)
 
     def get_task_nullspace(self, task):
         out = np.empty((49, self.B))

@@ -53,3 +53,107 @@ def test_cpp_facade_tick_matches_oracle(facade_bin, tmp_path):
     o.sim_step(ref, 0.001, substeps=2)
     qo, vo = o.get_state()
     assert np.abs(q1 - qo).max() < 1e-12 and np.abs(dq1 - vo).max() < 1e-10
+
+
+def _err(a, ref):
+    return (np.abs(a - ref).max(axis=0) / np.maximum(np.abs(ref).max(axis=0), 1)).max()
+
+
+@pytest.mark.gpu
+def test_cpp_example_04_task_and_redundancy(facade_bin, tmp_path):
+    """tests/cpp/facade_test.cpp::example04 = examples/04-task_and_redundancy.cpp:101-206 call for call (TemplateTask
+    virtuals, no RobotController); the same calls on the oracle, period by period in closed loop"""
+    import oracle_lib as ol
+
+    B, ticks = 64, 24
+    inp = pkg.workloads.make_inputs(3, B=B, seed=404)
+    path = tmp_path / "q.bin"
+    inp["q"].astype(np.float64).tofile(path)
+    r = subprocess.run([facade_bin, "example04", str(B), str(path), str(ticks)], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    out = np.frombuffer(r.stdout, dtype=np.float64).reshape(ticks + 1, 7, B)
+    o = ol.Oracle(ol.panda_model(), [ol.motion_force_task("motion_force_task"), ol.joint_task("joint_task", internal_otg=True)], B, threads=8)
+    o.set_state(inp["q"], np.zeros_like(inp["q"]))
+    o.reinitialize()
+    st = o.get_mft_status(0)
+    x0, R0 = st["pos"], st["rot"].reshape(3, 3, B)
+    wake = ticks // 3
+    for cycle in range(ticks):
+        t = 0.001 * cycle
+        o.task_update_model(0, None)
+        o.task_update_model(1, o.task_nullspaces(0)[2])
+        w_ori, amp = 2 * np.pi * 0.2, np.pi / 8
+        ang = amp * np.sin(w_ori * t)
+        c, s = np.cos(ang), np.sin(ang)
+        Rt = np.array([[c, 0, -s], [0, 1, 0], [s, 0, c]])
+        Rg = np.einsum("ik,kjb->ijb", Rt, R0).reshape(9, B)
+        wg, ag = np.zeros((3, B)), np.zeros((3, B))
+        wg[1], ag[1] = amp * w_ori * np.cos(w_ori * t), amp * w_ori * w_ori * -np.sin(w_ori * t)
+        r_, wc = 0.05, 2 * np.pi * 0.33
+        dp = np.array([0.0, np.sin(wc * t), 1 - np.cos(wc * t)])[:, None]
+        dv = np.array([0.0, np.cos(wc * t), np.sin(wc * t)])[:, None]
+        da = np.array([0.0, -np.sin(wc * t), np.cos(wc * t)])[:, None]
+        o.set_mft_goals(0, x0 + r_ * dp, Rg, np.broadcast_to(r_ * wc * dv, (3, B)), wg, np.broadcast_to(r_ * wc * wc * da, (3, B)), ag)
+        t0, t1 = o.task_compute_torques(0), o.task_compute_torques(1)
+        if cycle < wake:
+            t1 = np.zeros_like(t1)
+        if cycle == wake:
+            o.task_reinitialize(1)
+            g = inp["q"].copy()
+            g[0] += 1.5
+            o.set_jt_goals(1, g)
+        tau = t0 + t1
+        assert _err(out[cycle], tau) < 1e-9, (cycle, _err(out[cycle], tau))
+        o.sim_step(tau, 0.001, 1)
+    assert np.abs(out[ticks] - o.get_state()[0]).max() < 1e-10
+
+
+@pytest.mark.gpu
+def test_cpp_example_01_joint_control(facade_bin, tmp_path):
+    """tests/cpp/facade_test.cpp::example01 = examples/01-joint_control.cpp:123-191 call for call (BASELINE config 1)"""
+    import oracle_lib as ol
+
+    B, ticks = 64, 60
+    inp = pkg.workloads.make_inputs(3, B=B, seed=101)
+    path = tmp_path / "q.bin"
+    inp["q"].astype(np.float64).tofile(path)
+    r = subprocess.run([facade_bin, "example01", str(B), str(path), str(ticks)], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    out = np.frombuffer(r.stdout, dtype=np.float64).reshape(ticks + 1, 7, B)
+    cfg = ol.joint_task("joint_task", internal_otg=True)
+    o = ol.Oracle(ol.panda_model(), [cfg], B, threads=8)
+    o.set_state(inp["q"], np.zeros_like(inp["q"]))
+    o.reinitialize()
+
+    def gains(kp, kv):
+        for i in range(7):
+            cfg.kp[i], cfg.kv[i], cfg.ki[i] = kp, kv, 0.0
+        o.update_task_config(0, cfg)
+
+    gains(100, 20)
+    goal = inp["q"].copy()
+    cfg.use_internal_otg = 0
+    o.update_task_config(0, cfg)
+    eye = np.repeat(np.eye(7).reshape(49, 1), B, axis=1)
+    for cycle in range(ticks):
+        o.task_update_model(0, eye)
+        if cycle % 30 == 5:
+            goal[2] += 0.4
+            goal[3] -= 0.6
+        if cycle % 30 == 20:
+            goal[2] -= 0.4
+            goal[3] += 0.6
+        o.set_jt_goals(0, goal)
+        if cycle == 35:
+            gains(100, 10)
+        if cycle == 45:
+            cfg.use_velocity_saturation = 1
+            for i in range(7):
+                cfg.saturation_velocity[i] = np.pi / 4
+            o.update_task_config(0, cfg)
+        if cycle == 55:
+            gains(100, 20)
+        tau = o.task_compute_torques(0)
+        assert _err(out[cycle], tau) < 1e-9, (cycle, _err(out[cycle], tau))
+        o.sim_step(tau, 0.001, 1)
+    assert np.abs(out[ticks] - o.get_state()[0]).max() < 1e-10
