@@ -480,11 +480,9 @@ DI void popc_force(const DevTask& t, int B, int b, bool commit, const real* fd, 
 	}
 }
 
-DI void mft_law(const DevTask& t, const RobotCtx& rc, const real* J, const real* x, const real* R, MftIn& in, real* Fu,
-				real* Ff, int B = 0, int b = 0, bool commit = false) {
-	real v[3], w[3];
-	mv<3, N>(J, rc.dq, v);
-	mv<3, N>(J + 3 * N, rc.dq, w);
+// v, w: linear and angular velocity of the control frame (J dq, MotionForceTask.cpp:293-298)
+DI void mft_law_vw(const DevTask& t, const real* v, const real* w, const real* x, const real* R, MftIn& in, real* Fu, real* Ff,
+				   int B = 0, int b = 0, bool commit = false) {
 	if (t.plain_motion) {
 		// full task, no force space, world-frame gains, no velocity saturation: sigma_position =
 		// sigma_orientation = I, sigma_force = sigma_moment = 0 (MotionForceTask.cpp:431-436,463-467)
@@ -649,6 +647,13 @@ DI void mft_law(const DevTask& t, const RobotCtx& rc, const real* J, const real*
 		Ff[k] = f_force[k] + ff[k];
 		Ff[3 + k] = f_moment[k] + ff[3 + k];
 	}
+}
+DI void mft_law(const DevTask& t, const RobotCtx& rc, const real* J, const real* x, const real* R, MftIn& in, real* Fu,
+				real* Ff, int B = 0, int b = 0, bool commit = false) {
+	real v[3], w[3];
+	mv<3, N>(J, rc.dq, v);
+	mv<3, N>(J + 3 * N, rc.dq, w);
+	mft_law_vw(t, v, w, x, R, in, Fu, Ff, B, b, commit);
 }
 
 // (Jp A Jp^T) for a 6x7 Jp and symmetric 7x7 A

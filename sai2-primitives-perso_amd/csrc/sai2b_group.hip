@@ -1,0 +1,53 @@
+// sai2b_group.hip — the generic tick with a robot spread over G = 16 or 8 lanes (sai2b_group_tick.hpp): what runs
+// for hierarchies outside the SVD-free path, and for the robots that path hands over (its work list).
+#include <hip/hip_runtime.h>
+
+#include "sai2b_group_tick.hpp"
+#include "sai2b_launch.h"
+
+namespace sai2b {
+
+// fb_count == NULL: group i of the grid takes robot i. Otherwise the pass behind tick_fast_kernel: the groups
+// stride over the compacted work list fb_list[0 .. *fb_count) (the grid is sized for the machine, not for the list).
+template <int G, bool RANGE>
+__global__ __launch_bounds__(64) void tick_group_kernel(const DevParams* __restrict__ Pp, int commit_sh, int with_comp,
+														   int do_torque, const int* __restrict__ fb_count,
+														   const int* __restrict__ fb_list) {
+	constexpr int GPB = 64 / G;	 // robots per workgroup (one wavefront)
+	__shared__ real pads[GPB][N * (N | 1)];
+	const DevParams& P = *Pp;
+	const int gi = grp::group<G>();
+	if (fb_count) {
+		const int cnt = *(const gint*)fb_count;
+#pragma unroll 1
+		for (int e = blockIdx.x * GPB + gi; e < cnt; e += gridDim.x * GPB)
+			grp::tick_robot<G, RANGE>(P, ((const gint*)fb_list)[e], pads[gi], commit_sh, with_comp, do_torque);
+		return;
+	}
+	const int b = blockIdx.x * GPB + gi;
+	if (b >= P.B) return;
+	grp::tick_robot<G, RANGE>(P, b, pads[gi], commit_sh, with_comp, do_torque);
+}
+
+}  // namespace sai2b
+
+// lanes: 16 or 8. range_only: the pass ahead of the generator kernels (gated JointTasks)
+extern "C" int sai2b_launch_tick_group(const sai2b::DevParams* d_params, int B, int lanes, int range_only, int commit_sh, int with_comp,
+									   int do_torque, const int* fb_count, const int* fb_list, hipStream_t stream) {
+	const int gpb = 64 / lanes;
+	int blocks = (B + gpb - 1) / gpb;
+	if (fb_count && blocks > 4096) blocks = 4096;
+	const dim3 grid(blocks), block(64);
+	if (lanes == 16) {
+		if (range_only)
+			hipLaunchKernelGGL((sai2b::tick_group_kernel<16, true>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, fb_count, fb_list);
+		else
+			hipLaunchKernelGGL((sai2b::tick_group_kernel<16, false>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, fb_count, fb_list);
+	} else {
+		if (range_only)
+			hipLaunchKernelGGL((sai2b::tick_group_kernel<8, true>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, fb_count, fb_list);
+		else
+			hipLaunchKernelGGL((sai2b::tick_group_kernel<8, false>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, fb_count, fb_list);
+	}
+	return (int)hipGetLastError();
+}

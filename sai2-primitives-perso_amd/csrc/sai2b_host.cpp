@@ -31,6 +31,9 @@ struct sai2b_ctx {
 	bool params_dirty = true;
 	bool baked_model = false;  // the ctx model is bit-equal to the compile-time Panda constants
 	bool no_fast_path = false;	// SAI2B_NO_FAST_PATH=1 in the environment: always run the generic kernel
+	// lanes per robot of the generic kernel: SAI2B_GENERIC_LANES = 16 / 8 / 1 (1: the one-lane-per-robot kernel),
+	// default 0 = by the amount of work (generic_lanes())
+	int generic_lanes_env = 0;
 	int* fb_counts = nullptr;	// [2] robots the SVD-free kernel handed to the generic one (alternating by fb_parity)
 	int* fb_list = nullptr;		// [B] their indices
 	int fb_parity = 0;			// counter set of the last SVD-free launch
@@ -581,6 +584,7 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	ctx->model = *model;
 	const char* nf = std::getenv("SAI2B_NO_FAST_PATH");
 	ctx->no_fast_path = nf && nf[0] == '1';
+	if (const char* gl = std::getenv("SAI2B_GENERIC_LANES")) ctx->generic_lanes_env = std::atoi(gl);
 	DevParams& hp = ctx->h_params;
 	std::memset(&hp, 0, sizeof(hp));
 	hp.B = batch, hp.n_tasks = n_tasks;
@@ -893,6 +897,15 @@ static int fast_kind(const sai2b_ctx* ctx) {
 	return (ctx->cfg[1].type == SAI2B_JOINT_TASK && ctx->h_params.task[1].full_selection) ? 2 : 0;
 }
 
+// How many lanes a robot gets in the generic kernel (sai2b_group.hip). 16 = one DPP row per robot: the shortest
+// critical path, what the (usually short) work list behind the SVD-free kernel wants; 8 = two robots per row:
+// fewer idle lanes, better when the whole batch runs the generic kernel and fills the machine anyway.
+static int generic_lanes(const sai2b_ctx* ctx, bool whole_batch) {
+	if (ctx->generic_lanes_env == 1) return 0;
+	if (ctx->generic_lanes_env == 8 || ctx->generic_lanes_env == 16) return ctx->generic_lanes_env;
+	return (whole_batch && ctx->B >= 16384) ? 8 : 16;
+}
+
 static bool any_otg(const sai2b_ctx* ctx) {
 	for (int t = 0; t < ctx->T; t++)
 		if (ctx->h_params.task[t].otg_on) return true;
@@ -937,7 +950,7 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 	const int fast = fast_kind(ctx);
 	if (do_torque && gated) {
 		// which robots' gated tasks are active this tick: the task models of the current state, nothing committed
-		if (sai2b_launch_range_pass(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, with_comp, ctx->stream))
+		if (sai2b_launch_range_pass(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, with_comp, generic_lanes(ctx, true), ctx->stream))
 			return set_error(ctx, SAI2B_RUNTIME_ERROR, "task-range pass launch failed");
 		ctx->launches++;
 	}
@@ -951,7 +964,7 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 	}
 	const bool fast_launch = fast != 0 && !ctx->introspection && do_torque && commit_sh;
 	if (fast_launch) ctx->fb_parity ^= 1;
-	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, ctx->baked_model ? 1 : 0, commit_sh, with_comp, do_torque, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, ctx->stream))
+	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, ctx->baked_model ? 1 : 0, commit_sh, with_comp, do_torque, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, !fast_launch), ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
 	ctx->launches++;
 	if (do_torque) ctx->q_is_pose = true;  // computeTorques caches the tasks' current pose
@@ -1421,10 +1434,10 @@ extern "C" int sai2b_profile_tick(sai2b_ctx* ctx, int steps, double* first_ms, d
 	for (int s = 0; s < steps; s++) {
 		HIP_TRY(ctx, hipEventRecord(ev[3 * s], ctx->stream));
 		if (two) ctx->fb_parity ^= 1;
-		if (sai2b_launch_tick_part(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, ctx->baked_model ? 1 : 0, 0, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, ctx->stream))
+		if (sai2b_launch_tick_part(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, ctx->baked_model ? 1 : 0, 0, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, !two), ctx->stream))
 			return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
 		HIP_TRY(ctx, hipEventRecord(ev[3 * s + 1], ctx->stream));
-		if (two && sai2b_launch_tick_part(ctx->d_params, ctx->B, 0, fast, ctx->baked_model ? 1 : 0, 1, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, ctx->stream))
+		if (two && sai2b_launch_tick_part(ctx->d_params, ctx->B, 0, fast, ctx->baked_model ? 1 : 0, 1, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, false), ctx->stream))
 			return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
 		HIP_TRY(ctx, hipEventRecord(ev[3 * s + 2], ctx->stream));
 	}

@@ -297,16 +297,20 @@ static void launch_fast(int fast, int baked, dim3 grid, dim3 block, hipStream_t 
 }
 
 extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int commit_sh,
-								 int with_comp, int do_torque, int* fb_counts, int* fb_list, int parity, hipStream_t stream) {
+								 int with_comp, int do_torque, int* fb_counts, int* fb_list, int parity, int group, hipStream_t stream) {
 	const dim3 grid((B + 63) / 64), block(64);
 	// the fast path produces torques only: introspection and model-only passes use the generic kernel
 	if (debug) {
 		hipLaunchKernelGGL((sai2b::tick_kernel<true>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, nullptr, nullptr);
 	} else if (fast != 0 && do_torque && commit_sh) {
 		launch_fast(fast, baked, grid, block, stream, d_params, with_comp, fb_counts, fb_list, parity);
+		if (group)
+			return sai2b_launch_tick_group(d_params, B, group, 0, commit_sh, with_comp, do_torque, (const int*)(fb_counts + parity),
+										   (const int*)fb_list, stream);
 		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque,
 						   (const int*)(fb_counts + parity), (const int*)fb_list);
 	} else {
+		if (group) return sai2b_launch_tick_group(d_params, B, group, 0, commit_sh, with_comp, do_torque, nullptr, nullptr, stream);
 		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, nullptr, nullptr);
 	}
 	return (int)hipGetLastError();
@@ -314,8 +318,9 @@ extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int de
 
 // the range pass of hierarchies with gated generators (same DEBUG variant as the tick that follows, so that
 // both take the same range decisions)
-extern "C" int sai2b_launch_range_pass(const sai2b::DevParams* d_params, int B, int debug, int with_comp, hipStream_t stream) {
+extern "C" int sai2b_launch_range_pass(const sai2b::DevParams* d_params, int B, int debug, int with_comp, int group, hipStream_t stream) {
 	const dim3 grid((B + 63) / 64), block(64);
+	if (!debug && group) return sai2b_launch_tick_group(d_params, B, group, 1, 0, with_comp, 0, nullptr, nullptr, stream);
 	if (debug)
 		hipLaunchKernelGGL((sai2b::tick_kernel<true, true>), grid, block, 0, stream, d_params, 0, with_comp, 0, nullptr, nullptr);
 	else
@@ -324,12 +329,16 @@ extern "C" int sai2b_launch_range_pass(const sai2b::DevParams* d_params, int B, 
 }
 
 extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int part,
-									  int* fb_counts, int* fb_list, int parity, hipStream_t stream) {
+									  int* fb_counts, int* fb_list, int parity, int group, hipStream_t stream) {
 	const dim3 grid((B + 63) / 64), block(64);
 	if (debug)
 		hipLaunchKernelGGL((sai2b::tick_kernel<true>), grid, block, 0, stream, d_params, 1, 1, 1, nullptr, nullptr);
+	else if (fast == 0 && group)
+		return sai2b_launch_tick_group(d_params, B, group, 0, 1, 1, 1, nullptr, nullptr, stream);
 	else if (fast == 0)
 		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, 1, 1, 1, nullptr, nullptr);
+	else if (part == 1 && group)
+		return sai2b_launch_tick_group(d_params, B, group, 0, 1, 1, 1, (const int*)(fb_counts + parity), (const int*)fb_list, stream);
 	else if (part == 1)
 		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, 1, 1, 1, (const int*)(fb_counts + parity),
 						   (const int*)fb_list);

@@ -4,9 +4,13 @@
 
 #include "sai2b_params.h"
 
+// group: lanes per robot of the generic kernel (16 / 8), or 0 = the one-lane-per-robot generic kernel
 extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int commit_sh,
-								 int with_comp, int do_torque, int* fb_counts, int* fb_list, int parity, hipStream_t stream);
-extern "C" int sai2b_launch_range_pass(const sai2b::DevParams* d_params, int B, int debug, int with_comp, hipStream_t stream);
+								 int with_comp, int do_torque, int* fb_counts, int* fb_list, int parity, int group, hipStream_t stream);
+// generic tick with a robot spread over `lanes` = 16 or 8 lanes (sai2b_group.hip); fb_count / fb_list as tick_kernel
+extern "C" int sai2b_launch_tick_group(const sai2b::DevParams* d_params, int B, int lanes, int range_only, int commit_sh, int with_comp,
+									   int do_torque, const int* fb_count, const int* fb_list, hipStream_t stream);
+extern "C" int sai2b_launch_range_pass(const sai2b::DevParams* d_params, int B, int debug, int with_comp, int group, hipStream_t stream);
 // only_task < 0: every task (RobotController::reinitializeTasks); else TemplateTask::reInitializeTask of that one
 extern "C" int sai2b_launch_reinit(const sai2b::DevParams* d_params, int B, int only_task, hipStream_t stream);
 // one task on its own (TemplateTask.h:42-88): model update (do_torque = 0) or the task's torques (do_torque = 1) under
@@ -18,7 +22,7 @@ extern "C" int sai2b_launch_task(const sai2b::DevParams* d_params, int B, int ta
 // generic kernel over the work list of the SVD-free one. fb_counts: 2 ints, zero before the first
 // launch; fb_list: B ints; parity alternates 0/1 between consecutive launches of the SVD-free kernel
 extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int part,
-									  int* fb_counts, int* fb_list, int parity, hipStream_t stream);
+									  int* fb_counts, int* fb_list, int parity, int group, hipStream_t stream);
 // internal OTG (sai2b_otg.hip): one update of every enabled generator; (re)initialisation (modes in the kernel's comment)
 // task_mask bit t: advance task t's generator (all enabled ones: ~0)
 extern "C" int sai2b_launch_otg(const sai2b::DevParams* d_params, int B, int* counts, int* list, int parity, int clean_mask,
