@@ -5,12 +5,17 @@
 #include "sai2b_group_tick.hpp"
 #include "sai2b_launch.h"
 
+#ifndef SAI2B_GROUP_WAVES
+#define SAI2B_GROUP_WAVES 1
+#endif
+#define SAI2B_GROUP_OCC __attribute__((amdgpu_waves_per_eu(SAI2B_GROUP_WAVES, SAI2B_GROUP_WAVES)))
+
 namespace sai2b {
 
 // fb_count == NULL: group i of the grid takes robot i. Otherwise the pass behind tick_fast_kernel: the groups
 // stride over the compacted work list fb_list[0 .. *fb_count) (the grid is sized for the machine, not for the list).
 template <int G, bool RANGE>
-__global__ __launch_bounds__(64) void tick_group_kernel(const DevParams* __restrict__ Pp, int commit_sh, int with_comp,
+__global__ __launch_bounds__(64) SAI2B_GROUP_OCC void tick_group_kernel(const DevParams* __restrict__ Pp, int commit_sh, int with_comp,
 														   int do_torque, const int* __restrict__ fb_count,
 														   const int* __restrict__ fb_list) {
 	constexpr int GPB = 64 / G;	 // robots per workgroup (one wavefront)
@@ -30,6 +35,21 @@ __global__ __launch_bounds__(64) void tick_group_kernel(const DevParams* __restr
 }
 
 }  // namespace sai2b
+
+#ifdef SAI2B_GROUP_STAMP
+// diagnostic build only (scripts/micro/group_stamps.py)
+extern "C" void sai2b_debug_reset_stamps() {
+	int zero = 0;
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(sai2b::grp::g_stamp_n), &zero, sizeof(int));
+}
+extern "C" int sai2b_debug_read_stamps(unsigned long long* out, int cap) {
+	int n = 0;
+	(void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(sai2b::grp::g_stamp_n), sizeof(int));
+	if (2 * n > cap) n = cap / 2;
+	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(sai2b::grp::g_stamps), sizeof(unsigned long long) * 2 * n);
+	return n;
+}
+#endif
 
 // lanes: 16 or 8. range_only: the pass ahead of the generator kernels (gated JointTasks)
 extern "C" int sai2b_launch_tick_group(const sai2b::DevParams* d_params, int B, int lanes, int range_only, int commit_sh, int with_comp,

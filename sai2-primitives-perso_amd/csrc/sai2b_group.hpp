@@ -193,8 +193,9 @@ DI real sqrt_nr(real x) {
 // r < n; lanes >= n must hold zero rows and come out as zero rows. Stands in for Eigen's .inverse() on the SPD
 // matrices of the path (SingularityHandler.cpp:120,182,190,201,212, JointTask.cpp:260-265, sai2-model M^-1).
 template <int G, int n, int k>
-DI void spd_inverse_step(real* a, int r) {
+DI void spd_inverse_step(real* a, int r, int kmax) {
 	if constexpr (k < n) {
+		if (k < kmax) {	 // uniform over the wavefront
 		const real d = recip(bcast<G, k>(a[k]));
 		const bool me = (r == k);
 		// the pivot row is scaled in its own lane; the others subtract f times it
@@ -203,12 +204,15 @@ DI void spd_inverse_step(real* a, int r) {
 		UNROLL for (int j = 0; j < n; j++) a[j] *= sc;
 		selffma<G, k, n>(a, nf);  // a[j] += bcast_k(a[j]) * nf   (column k comes out as 0 in the other rows)
 		a[k] = me ? d : nf * d;	  // ... and is replaced by the column of the inverse being built
-		spd_inverse_step<G, n, k + 1>(a, r);
+		}
+		spd_inverse_step<G, n, k + 1>(a, r, kmax);
 	}
 }
+// kmax < n (the same for every robot of the launch): rows and columns >= kmax of A are those of the identity (A is
+// block diagonal), whose elimination steps change nothing and are skipped
 template <int G, int n>
-DI void spd_inverse_rows(real* a) {
-	spd_inverse_step<G, n, 0>(a, lane<G>());
+DI void spd_inverse_rows(real* a, int kmax = n) {
+	spd_inverse_step<G, n, 0>(a, lane<G>(), kmax);
 }
 
 }  // namespace grp

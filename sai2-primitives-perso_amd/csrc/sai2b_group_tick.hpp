@@ -16,6 +16,29 @@ namespace sai2b {
 namespace grp {
 
 DI real kd(int r, int j) { return r == j ? 1.0 : 0.0; }
+#define SAI2B_TASK_FN DI
+// scheduling fence + a named comment in the ISA (static per-phase instruction counts: scripts/count_group_phases.py).
+// -DSAI2B_GROUP_STAMP: lane 0 of workgroup 0 also records (id, s_memtime) at every mark into g_stamps (read back
+// by scripts/micro/group_stamps.py): where one robot's cycles go.
+#ifdef SAI2B_GROUP_STAMP
+__device__ unsigned long long g_stamps[512];
+__device__ int g_stamp_n;
+#define GMARK(id, name)                                                                        \
+	do {                                                                                       \
+		__builtin_amdgcn_sched_barrier(0);                                                     \
+		if (blockIdx.x == 0 && threadIdx.x == 0) {                                             \
+			const int k_ = g_stamp_n;                                                          \
+			if (k_ < 255) {                                                                    \
+				g_stamps[2 * k_] = (unsigned long long)(id);                                   \
+				g_stamps[2 * k_ + 1] = __builtin_readcyclecounter();                           \
+				g_stamp_n = k_ + 1;                                                            \
+			}                                                                                  \
+		}                                                                                      \
+		__builtin_amdgcn_sched_barrier(0);                                                     \
+	} while (0)
+#else
+#define GMARK(id, name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; GMARK " name); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
 
 // per-lane view of one robot
 struct Rob {
@@ -158,14 +181,15 @@ DI bool certify_rows(const real* g, const real* pc, real abs2, real rel2) {
 }
 
 // U_x (U_x^T A U_x)^-1 U_x^T for the orthogonal projector Pi (rows in lanes), A symmetric: pinv_proj of sai2b_device.hpp
+// kmax < n: Pi = diag(1 x kmax, 0 ...) for every robot of the launch (see spd_inverse_rows)
 template <int G, int n>
-DI void pinv_proj_rows(const real* A, const real* Pi, real* out) {
+DI void pinv_proj_rows(const real* A, const real* Pi, real* out, int kmax = n) {
 	const int r = lane<G>();
 	real T[n];
 	mm_rr<G, n, n>(Pi, A, T);
 	mm_rr<G, n, n>(T, Pi, out);
 	UNROLL for (int j = 0; j < n; j++) out[j] += (r < n) ? kd(r, j) - Pi[j] : 0.0;
-	spd_inverse_rows<G, n>(out);
+	spd_inverse_rows<G, n>(out, kmax);
 	UNROLL for (int j = 0; j < n; j++) out[j] -= (r < n) ? kd(r, j) - Pi[j] : 0.0;
 }
 // (Jp A Jp^T): rows of Jp (m x N) in lanes, A symmetric N x N rows in lanes; T1 = Jp A is returned too
@@ -179,16 +203,21 @@ DI void sandwich_rows(const real* jp, const real* A, real* t1, real* out) {
 // X (N x C): row r in lane r; W (C x C, rotations accumulated, starts as I): row i in lane i < C. Same cyclic order,
 // threshold and rotation formula as hestenes() of sai2b_device.hpp / the oracle; the column norms are carried
 // (refreshed every sweep) instead of recomputed for every pair.
+// ncols (the same for every robot of the launch): columns >= ncols of X are exactly zero and are left alone.
 template <int G, int C>
-DI void jacobi_rows(real* x, real* w) {
+DI void jacobi_rows(real* x, real* w, int ncols = C) {
 	const int r = lane<G>();
 	UNROLL for (int j = 0; j < C; j++) w[j] = (r < C) ? kd(r, j) : 0.0;
 #pragma unroll 1
 	for (int sweep = 0; sweep < 60; sweep++) {
 		real d[C];
-		UNROLL for (int j = 0; j < C; j++) d[j] = allsum<G, N>(x[j] * x[j]);
+		UNROLL for (int j = 0; j < C; j++) {
+			d[j] = 0;
+			if (j < ncols) d[j] = allsum<G, N>(x[j] * x[j]);
+		}
 		bool rotated = false;
 		UNROLL for (int i = 0; i < C - 1; i++) UNROLL for (int j = i + 1; j < C; j++) {
+			if (j >= ncols) continue;  // uniform over the wavefront: a scalar branch around the pair
 			const real ga = allsum<G, N>(x[i] * x[j]);
 			const real al = d[i], be = d[j];
 			const bool rot = fabs(ga) > 1e-15 * sqrt_nr(al * be);
@@ -228,6 +257,28 @@ DI void chain_append_g(ChainG& ch, const real* rows, int nrows) {
 	ch.wrows += nrows;
 }
 
+// rows of an n-row matrix (row j in lane j) picked by src_of(slot) into the lanes after the chain's rows: lane
+// wrows + m receives the row of lane `src` where `src` was chosen by the caller for slot m = r - wrows
+template <int G>
+DI void chain_append_from(ChainG& ch, const real* rows, int src, int count) {
+	const int r = lane<G>();
+	const bool hit = r >= ch.wrows && r < ch.wrows + count;
+	UNROLL for (int j = 0; j < N; j++) {
+		const real v = gather<G>(rows[j], hit ? src : 0);
+		ch.W[j] = hit ? v : ch.W[j];
+	}
+	ch.wrows += count;
+	if (ch.wrows > N) ch.ok = false;
+}
+// one replicated row (the same values in every lane) appended to the chain
+template <int G>
+DI void chain_append_row(ChainG& ch, const real* row) {
+	const int r = lane<G>();
+	UNROLL for (int j = 0; j < N; j++) ch.W[j] = (r == ch.wrows) ? row[j] : ch.W[j];
+	ch.wrows += 1;
+	if (ch.wrows > N) ch.ok = false;
+}
+
 // N_prec^T <- N_prec^T N^T  (RobotController.cpp:58, MotionForceTask.h:207-209)
 template <int G>
 DI void nprec_update(bool first, const real* ntaskT, real* nprecT) {
@@ -251,11 +302,12 @@ DI void nullspace_T(const real* jpT, const real* L, const real* t1, int r, real*
 // ------------------------------------------------------------------ MotionForceTask (MotionForceTask.cpp:247-509,
 // SingularityHandler.cpp:75-368): mft_task of sai2b_device.hpp, rows in lanes. tau: this lane's component.
 template <int G>
-DI void mft_task_g(const DevParams& P, const DevTask& t, const Rob& rb, bool first, bool last, bool commit_sh, bool do_torque,
+SAI2B_TASK_FN void mft_task_g(const DevParams& P, const DevTask& t, const Rob& rb, bool first, bool last, bool commit_sh, bool do_torque,
 				   real* nprecT, real& tau_total, ChainG& chain) {
 	const int r = rb.r, B = rb.B, b = rb.b;
 	const bool r6 = r < 6, rN = r < N;
 	real x[3], R[9];
+	GMARK(0, "mft_begin");
 	frame_pose_g<G>(t, rb.FR, rb.Fp, x, R);
 	// Jacobian column of this lane's joint (JWorldFrame, linear rows first), projected: J = P Jw
 	real jT[6];
@@ -283,6 +335,7 @@ DI void mft_task_g(const DevParams& P, const DevTask& t, const Rob& rb, bool fir
 		mm_rr<G, N, 6>(nprecT, jT, jpT);
 	}
 	transpose_lds<G, N, 6>(rb.pad, jpT, jp);
+	GMARK(1, "mft_jp_done");
 	// ---- branch decision (SingularityHandler.cpp:83-143): SVD-free certificate first, per robot
 	const int rank = t.rank;
 	real g6[6], pns[6], ps[6], Prow[6];
@@ -295,6 +348,7 @@ DI void mft_task_g(const DevParams& P, const DevTask& t, const Rob& rb, bool fir
 		UNROLL for (int k = 0; k < 6; k++) pc[k] = r6 ? kd(r, k) - Prow[k] : 0.0;
 		certified = certify_rows<G, 6>(g6, t.full_projection ? nullptr : pc, t.s_abs_tol * t.s_abs_tol, t.s_max * t.s_max);
 	}
+	GMARK(2, "mft_cert_done");
 	real x6[6], w6[6], sv[6], alpha = 1;
 	int pos[6], split = rank;
 	UNROLL for (int i = 0; i < 6; i++) {
@@ -316,11 +370,23 @@ DI void mft_task_g(const DevParams& P, const DevTask& t, const Rob& rb, bool fir
 			chain_append_g<G>(chain, rows, rank);
 		}
 	} else {
-		chain.ok = false;
-		// ---- thin SVD of Jp via one-sided Jacobi on Jp^T (N x 6): Jp^T W = Q, U = W, V = Q / s
-		UNROLL for (int i = 0; i < 6; i++) x6[i] = jpT[i];
-		jacobi_rows<G, 6>(x6, w6);
-		UNROLL for (int j = 0; j < 6; j++) sv[j] = sqrt_nr(allsum<G, N>(x6[j] * x6[j]));
+		// ---- thin SVD of Jp via one-sided Jacobi on Jp^T (N x 6): Jp^T W = Q, U = W, V = Q / s. A partial task is
+		// rotated into the basis PU of range(P) first: Jp^T PU has exactly `rank` non-zero columns, the pairs of the
+		// others are skipped, and U = PU W'
+		if (t.full_projection) {
+			UNROLL for (int i = 0; i < 6; i++) x6[i] = jpT[i];
+			jacobi_rows<G, 6>(x6, w6);
+		} else {
+			mv_t<6, 6>(t.PU, jpT, x6);	// x6[c] = sum_k jpT[k] PU[k][c]
+			real wp[6], pu[6];
+			jacobi_rows<G, 6>(x6, wp, rank);
+			UNROLL for (int k = 0; k < 6; k++) pu[k] = r6 ? t.PU[r5 * 6 + k] : 0.0;	 // row r of PU
+			mm_rr<G, 6, 6>(pu, wp, w6);
+		}
+		UNROLL for (int j = 0; j < 6; j++) {
+			sv[j] = 0;
+			if (j < rank) sv[j] = sqrt_nr(allsum<G, N>(x6[j] * x6[j]));
+		}
 		real ss[6];
 		UNROLL for (int j = 0; j < 6; j++) {
 			int p = 0;
@@ -358,18 +424,30 @@ DI void mft_task_g(const DevParams& P, const DevTask& t, const Rob& rb, bool fir
 			mm_rt<G, 6, 6>(wa, w6, pns);
 			mm_rt<G, 6, 6>(wb, w6, ps);
 		}
+		if (chain.ok && split > 0) {
+			// row space of the non-singular part for a later full JointTask: U_ns^T Jp, the columns ranked < split
+			real uT[6], rows6[N];
+			transpose_lds<G, 6, 6>(rb.pad, w6, uT);
+			mm_rr<G, 6, N>(uT, jp, rows6);	// lane j: (U^T Jp)[j][:]
+			const int slot = r - chain.wrows;
+			int src = 0;
+			UNROLL for (int j = 0; j < 6; j++) src = (pos[j] == slot) ? j : src;
+			chain_append_from<G>(chain, rows6, src, split);
+		}
 	}
+	GMARK(3, "mft_branch_done");
 	const int sc = rank - split;
 	const bool bie = t.decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES;
 	const bool impedance = t.decoupling == SAI2B_IMPEDANCE;
 	// ---- non-singular part: Lambda_ns (embedded), N_ns (SingularityHandler.cpp:110-114,130-134)
 	real A[6], AB[6], t1[N], lns[6], lnsMod[6], nnsT[N];
+	const int kmax6 = (split == rank) ? t.p_lead : 6;  // pns == P == diag(1 x p_lead, 0 ...)
 	sandwich_rows<G, 6>(jp, rb.minv, t1, A);
-	pinv_proj_rows<G, 6>(A, pns, lns);
+	pinv_proj_rows<G, 6>(A, pns, lns, kmax6);
 	if (bie) {
 		real t1b[N];
 		sandwich_rows<G, 6>(jp, rb.minvB, t1b, AB);
-		pinv_proj_rows<G, 6>(AB, pns, lnsMod);
+		pinv_proj_rows<G, 6>(AB, pns, lnsMod, kmax6);
 	} else {
 		UNROLL for (int i = 0; i < 6; i++) {
 			AB[i] = A[i];
@@ -377,6 +455,7 @@ DI void mft_task_g(const DevParams& P, const DevTask& t, const Rob& rb, bool fir
 		}
 	}
 	nullspace_T<G, 6>(jpT, lns, t1, r, nnsT);
+	GMARK(4, "mft_lambda_done");
 	// ---- control law (replicated in every lane)
 	real Fu[6], Ff[6];
 	{
@@ -393,6 +472,7 @@ DI void mft_task_g(const DevParams& P, const DevTask& t, const Rob& rb, bool fir
 		UNROLL for (int k = 0; k < 6; k++) a6 = fma(lnsMod[k], Fu[k], fma(pns[k], Ff[k], a6));
 		tau = mv<G, 6>(jpT, a6);  // SingularityHandler.cpp:307-309
 	}
+	GMARK(5, "mft_law_done");
 	// ---- singularity bookkeeping (SingularityHandler.cpp:230-295) and blended torques (:313-367)
 	int* IS = t.istate;
 	real* S = t.state;
@@ -510,6 +590,21 @@ DI void mft_task_g(const DevParams& P, const DevTask& t, const Rob& rb, bool fir
 				mm_rr<G, N, N>(nprecT, nnsT, bmT);
 			}
 			transpose_lds<G, N, N>(rb.pad, bmT, bm);
+			if (chain.ok) {
+				// ... and of the posture task: the rows V_s^T Bm, one per singular column
+#pragma unroll 1
+				for (int p = split; p < rank; p++) {
+					real v = 0, s_ = 0, row[N];
+					UNROLL for (int j = 0; j < 6; j++) {
+						const bool hit = pos[j] == p;
+						s_ = hit ? sv[j] : s_;
+						v = hit ? x6[j] : v;
+					}
+					v = (rN && s_ > 0) ? v / s_ : 0.0;
+					UNROLL for (int c = 0; c < N; c++) row[c] = allsum<G, N>(v * bm[c]);
+					chain_append_row<G>(chain, row);
+				}
+			}
 			real C[N], tb[N], lj[N], ljMod[N];
 			sandwich_rows<G, N>(bm, rb.minv, tb, C);
 			pinv_proj_rows<G, N>(C, pv, lj);
@@ -570,17 +665,20 @@ DI void mft_task_g(const DevParams& P, const DevTask& t, const Rob& rb, bool fir
 		}
 	}
 	tau_total += rN ? tau : 0.0;
+	GMARK(6, "mft_sing_done");
 	if (!last) nprec_update<G>(first, ntaskT, nprecT);
+	GMARK(7, "mft_end");
 }
 
 // ------------------------------------------------------------------ JointTask (JointTask.cpp:218-356): jt_task of
 // sai2b_device.hpp, rows in lanes
 template <int G, bool RANGE_ONLY = false>
-DI void jt_task_g(const DevParams& P, const DevTask& t, const Rob& rb, bool first, bool last, bool with_comp, bool do_torque,
+SAI2B_TASK_FN void jt_task_g(const DevParams& P, const DevTask& t, const Rob& rb, bool first, bool last, bool with_comp, bool do_torque,
 				  real* nprecT, real& tau_total, ChainG& chain) {
 	const int r = rb.r, B = rb.B, b = rb.b;
 	const bool rN = r < N, rk = r < t.k0;
 	const int rs = rk ? r : 0;
+	GMARK(8, "jt_begin");
 	// Jp = S N_prec: its transpose column by column is local (S is batch-uniform); rows through the pad
 	real jpT[N], jp[N], srow[N];
 	UNROLL for (int l = 0; l < N; l++) srow[l] = rk ? t.S[rs * N + l] : 0.0;  // row r of S
@@ -596,11 +694,14 @@ DI void jt_task_g(const DevParams& P, const DevTask& t, const Rob& rb, bool firs
 		}
 		transpose_lds<G, N, N>(rb.pad, jpT, jp);
 	}
+	GMARK(9, "jt_jp_done");
 	// range projector of Jp (Sai2Model::matrixRangeBasis, tolerance 1e-3: SURVEY App. D), rows in lanes
 	real PR[N];
 	bool zero_range = false, need_svd = false;
+	int pr_lead = N;  // PR == diag(1 x pr_lead, 0 ...): the 7 x 7 eliminations stop there
 	if (first) {
 		UNROLL for (int j = 0; j < N; j++) PR[j] = rk ? kd(r, j) : 0.0;
+		pr_lead = t.k0;
 		if (chain.ok) chain_append_g<G>(chain, jp, t.k0);
 	} else if (t.full_selection && chain.ok) {
 		// Jp = N_prec behind certified tasks: range(N_prec) = null(W)
@@ -621,6 +722,7 @@ DI void jt_task_g(const DevParams& P, const DevTask& t, const Rob& rb, bool firs
 		UNROLL for (int j = 0; j < N; j++) pc[j] = (rN && !rk) ? kd(r, j) : 0.0;
 		if (certify_rows<G, N>(c0, pc, 1e-6, 1e-6)) {
 			UNROLL for (int j = 0; j < N; j++) PR[j] = rk ? kd(r, j) : 0.0;
+			pr_lead = t.k0;
 			if (chain.ok) chain_append_g<G>(chain, jp, t.k0);
 		} else {
 			need_svd = true;
@@ -629,29 +731,44 @@ DI void jt_task_g(const DevParams& P, const DevTask& t, const Rob& rb, bool firs
 		need_svd = true;
 	}
 	if (need_svd) {
-		chain.ok = false;
 		// left singular vectors of Jp = the rotations of the one-sided Jacobi on Jp^T (N x N, columns >= k0 zero)
 		real X[N], W[N], sv[N];
 		UNROLL for (int j = 0; j < N; j++) X[j] = jpT[j];
-		jacobi_rows<G, N>(X, W);
+		jacobi_rows<G, N>(X, W, t.k0);
 		real s0 = 0;
 		UNROLL for (int j = 0; j < N; j++) {
-			sv[j] = sqrt_nr(allsum<G, N>(X[j] * X[j]));
+			sv[j] = 0;
+			if (j < t.k0) sv[j] = sqrt_nr(allsum<G, N>(X[j] * X[j]));
 			s0 = fmax(s0, sv[j]);
 		}
 		zero_range = s0 < 1e-3;
 		int dof = 0;
 		real wa[N];
+		bool keep[N];
 		UNROLL for (int j = 0; j < N; j++) {
-			const bool keep = sv[j] / s0 >= 1e-3;
-			dof += keep ? 1 : 0;
-			wa[j] = keep ? W[j] : 0.0;
+			keep[j] = !zero_range && sv[j] / s0 >= 1e-3;
+			dof += keep[j] ? 1 : 0;
+			wa[j] = keep[j] ? W[j] : 0.0;
 		}
 		mm_rt<G, N, N>(wa, W, PR);
 		if (dof == t.k0) {	// full row rank -> identity basis
 			UNROLL for (int j = 0; j < N; j++) PR[j] = rk ? kd(r, j) : 0.0;
+			pr_lead = t.k0;
+		}
+		if (chain.ok && dof > 0) {	// row space of the task: R^T Jp, the kept columns in order
+			real uT[N], rowsN[N];
+			transpose_lds<G, N, N>(rb.pad, W, uT);
+			mm_rr<G, N, N>(uT, jp, rowsN);	// lane j: (W^T Jp)[j][:]
+			const int slot = r - chain.wrows;
+			int src = 0, cnt = 0;
+			UNROLL for (int j = 0; j < N; j++) {
+				src = (keep[j] && cnt == slot) ? j : src;
+				cnt += keep[j] ? 1 : 0;
+			}
+			chain_append_from<G>(chain, rowsN, src, dof);
 		}
 	}
+	GMARK(10, "jt_range_done");
 	if (t.otg_gated && !do_torque) st(t.otg_state, OTG_ACTIVE, B, b, zero_range ? 0.0 : 1.0);	 // read by otg_kernel
 	if constexpr (RANGE_ONLY) return;
 	real tau = 0, ntaskT[N];
@@ -685,11 +802,11 @@ DI void jt_task_g(const DevParams& P, const DevTask& t, const Rob& rb, bool firs
 		}
 		real C[N], t1[N], L[N], LMod[N];
 		sandwich_rows<G, N>(jp, rb.minv, t1, C);
-		pinv_proj_rows<G, N>(C, PR, L);
+		pinv_proj_rows<G, N>(C, PR, L, pr_lead);
 		if (t.decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES) {
 			real t1b[N];
 			sandwich_rows<G, N>(jp, rb.minvB, t1b, C);
-			pinv_proj_rows<G, N>(C, PR, LMod);
+			pinv_proj_rows<G, N>(C, PR, LMod, pr_lead);
 		} else {
 			UNROLL for (int j = 0; j < N; j++) LMod[j] = (t.decoupling == SAI2B_IMPEDANCE) ? PR[j] : L[j];
 		}
@@ -701,10 +818,12 @@ DI void jt_task_g(const DevParams& P, const DevTask& t, const Rob& rb, bool firs
 			xa -= mv<G, N>(L, b7);
 		}
 		tau = mv<G, N>(jpT, xa);
+		GMARK(11, "jt_torque_done");
 		if (!last) nullspace_T<G, N>(jpT, L, t1, r, ntaskT);
 	}
 	tau_total += rN ? tau : 0.0;
 	if (!last) nprec_update<G>(first, ntaskT, nprecT);
+	GMARK(12, "jt_end");
 }
 
 // ------------------------------------------------------------------ one robot's tick
@@ -722,13 +841,17 @@ DI void tick_robot(const DevParams& P, int b, real* pad, int commit_sh, int with
 	rb.q = rN ? ld(P.q, rs, B, b) : 0.0;
 	rb.dq = rN ? ld(P.dq, rs, B, b) : 0.0;
 	real g = 0;
+	GMARK(13, "model_begin");
 	{
 		// Sai2Model::updateModel(): kinematics, M (CRBA), M^-1 (examples/05-using_robot_controller.cpp:143-145)
 		fk_scan<G>(P.model, rb.r, rb.q, rb.FR, rb.Fp);
+		GMARK(14, "model_fk_done");
 		real Mrow[N];
 		crba_g<G>(P.model, rb.r, rb.FR, rb.Fp, Mrow, P.gravity_comp != 0, &g);
+		GMARK(15, "model_crba_done");
 		UNROLL for (int j = 0; j < N; j++) rb.minv[j] = Mrow[j];
 		spd_inverse_rows<G, N>(rb.minv);
+		GMARK(16, "model_minv_done");
 		// bounded inertia estimate (SingularityHandler.cpp:176-182, JointTask.cpp:254-260), shared
 		bool any_bie = false;
 		real thr = 0;
@@ -744,6 +867,7 @@ DI void tick_robot(const DevParams& P, int b, real* pad, int commit_sh, int with
 			UNROLL for (int j = 0; j < N; j++) rb.minvB[j] = rb.minv[j];
 		}
 	}
+	GMARK(17, "model_end");
 	real nprecT[N], tau = 0;
 	UNROLL for (int j = 0; j < N; j++) nprecT[j] = rN ? kd(rb.r, j) : 0.0;
 	ChainG chain;

@@ -453,6 +453,20 @@ static void fill_dev_task(const sai2b_task_config& c, DevTask& d) {
 		if (c.partial_projection[i] != ((i % 7 == 0) ? 1.0 : 0.0)) pid = false;
 	d.full_projection = pid ? 1 : 0;
 	d.rank = c.pos_range + c.ori_range;
+	{
+		int lead = 0;
+		bool diag01 = true;
+		for (int i = 0; i < 6; i++)
+			for (int j = 0; j < 6; j++) {
+				const double v = c.partial_projection[i * 6 + j];
+				if (i != j && v != 0.0) diag01 = false;
+				if (i == j && v != 0.0 && v != 1.0) diag01 = false;
+			}
+		while (lead < 6 && c.partial_projection[lead * 7] == 1.0) lead++;
+		for (int i = lead; i < 6; i++)
+			if (c.partial_projection[i * 7] != 0.0) diag01 = false;
+		d.p_lead = diag01 ? lead : 6;
+	}
 	{  // basis of range(P): eigenvectors of the projector with eigenvalue 1
 		double w[6], V[36];
 		sym_eig(6, c.partial_projection, w, V);

@@ -40,6 +40,7 @@ struct DevTask {
 	double P[36];
 	double PU[36];	// orthonormal basis of range(P) in its first `rank` columns (row-major 6x6), rest zero
 	int rank; // pos_range + ori_range
+	int p_lead;	 // P == diag(1 x p_lead, 0 ...) exactly (then == rank); else 6: lets the 6 x 6 eliminations stop early
 	int in_frame;
 	double kp_pos[3], kv_pos[3], ki_pos[3], kp_ori[3], kv_ori[3], ki_ori[3];
 	double kp_f[3], kv_f[3], ki_f[3], kp_m[3], kv_m[3], ki_m[3];
