@@ -16,6 +16,9 @@ namespace sai2b {
 namespace grp {
 
 DI real kd(int r, int j) { return r == j ? 1.0 : 0.0; }
+// `on ? v : 0` where v is a memory operand: the load itself must not be conditional (the compiler cannot speculate
+// it and would wrap every single one in an exec-mask branch); indices are clamped by the caller
+DI real sel0(bool on, real v) { return on ? v : 0.0; }
 #define SAI2B_TASK_FN DI
 // scheduling fence + a named comment in the ISA (static per-phase instruction counts: scripts/count_group_phases.py).
 // -DSAI2B_GROUP_STAMP: lane 0 of workgroup 0 also records (id, s_memtime) at every mark into g_stamps (read back
@@ -36,8 +39,10 @@ __device__ int g_stamp_n;
 		}                                                                                      \
 		__builtin_amdgcn_sched_barrier(0);                                                     \
 	} while (0)
-#else
+#elif defined(SAI2B_GROUP_MARKS)
 #define GMARK(id, name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; GMARK " name); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GMARK(id, name) do { } while (0)
 #endif
 
 // per-lane view of one robot
@@ -73,7 +78,7 @@ DI void fk_scan(const DevModel& md, int r, real q, real* R, real* p) {
 		R[3 * k + 0] = act ? fma(c, e0, s * e1) : kd(k, 0);
 		R[3 * k + 1] = act ? fma(c, e1, -s * e0) : kd(k, 1);
 		R[3 * k + 2] = act ? e2 : kd(k, 2);
-		p[k] = act ? md.xyz[rr][k] : 0.0;
+		p[k] = sel0(act, md.xyz[rr][k]);
 	}
 	fk_scan_step<G, 1>(R, p);
 	fk_scan_step<G, 2>(R, p);
@@ -105,7 +110,7 @@ DI void crba_g(const DevModel& md, int r, const real* R, const real* p, real* Mr
 		const real l0 = li[0], l1 = li[1], l2 = li[2], l3 = li[3], l4 = li[4], l5 = li[5];
 		real Il[9] = {l0, l3, l4, l3, l1, l5, l4, l5, l2}, T[9];
 		mm<3, 3, 3>(R, Il, T);
-		const real m = act ? md.mass[rr] : 0.0;
+		const real m = sel0(act, md.mass[rr]);
 		const real c2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
 		const int ia[6] = {0, 1, 2, 0, 0, 1}, ib[6] = {0, 1, 2, 1, 2, 2};
 		UNROLL for (int e = 0; e < 6; e++) {
@@ -220,20 +225,21 @@ DI void jacobi_rows(real* x, real* w, int ncols = C) {
 			if (j >= ncols) continue;  // uniform over the wavefront: a scalar branch around the pair
 			const real ga = allsum<G, N>(x[i] * x[j]);
 			const real al = d[i], be = d[j];
-			const bool rot = fabs(ga) > 1e-15 * sqrt_nr(al * be);
-			rotated = rotated || rot;
-			const real gs = rot ? ga : 1.0;
-			const real zeta = (be - al) * (0.5 * recip(gs));
-			const real t = copysign(1.0, zeta) * recip(fabs(zeta) + sqrt_nr(fma(zeta, zeta, 1.0)));
-			const real cr = rsqrt_nr(fma(t, t, 1.0));
-			const real c = rot ? cr : 1.0, s = rot ? cr * t : 0.0;
-			const real xi = x[i], xj = x[j], wi = w[i], wj = w[j];
-			x[i] = c * xi - s * xj;
-			x[j] = s * xi + c * xj;
-			w[i] = c * wi - s * wj;
-			w[j] = s * wi + c * wj;
-			d[i] = rot ? fma(-t, ga, al) : al;
-			d[j] = rot ? fma(t, ga, be) : be;
+			// |ga| > 1e-15 sqrt(al be), without the square root (the same for every lane of the robot's group)
+			const bool rot = ga * ga > 1e-30 * (al * be);
+			if (rot) {	// no cross-lane operation inside: robots of the wavefront that are done with this pair idle
+				rotated = true;
+				const real zeta = (be - al) * (0.5 * recip(ga));
+				const real t = copysign(1.0, zeta) * recip(fabs(zeta) + sqrt_nr(fma(zeta, zeta, 1.0)));
+				const real c = rsqrt_nr(fma(t, t, 1.0)), s = c * t;
+				const real xi = x[i], xj = x[j], wi = w[i], wj = w[j];
+				x[i] = c * xi - s * xj;
+				x[j] = s * xi + c * xj;
+				w[i] = c * wi - s * wj;
+				w[j] = s * wi + c * wj;
+				d[i] = fma(-t, ga, al);
+				d[j] = fma(t, ga, be);
+			}
 		}
 		if (!rotated) break;
 	}
@@ -341,7 +347,7 @@ SAI2B_TASK_FN void mft_task_g(const DevParams& P, const DevTask& t, const Rob& r
 	real g6[6], pns[6], ps[6], Prow[6];
 	mm_rt<G, N, 6>(jp, jp, g6);
 	const int r5 = r6 ? r : 0;
-	UNROLL for (int k = 0; k < 6; k++) Prow[k] = r6 ? t.P[r5 * 6 + k] : 0.0;
+	UNROLL for (int k = 0; k < 6; k++) Prow[k] = sel0(r6, t.P[r5 * 6 + k]);
 	bool certified;
 	{
 		real pc[6];
@@ -364,7 +370,7 @@ SAI2B_TASK_FN void mft_task_g(const DevParams& P, const DevTask& t, const Rob& r
 				UNROLL for (int j = 0; j < N; j++) rows[j] = jp[j];
 			} else {
 				real pu[6];
-				UNROLL for (int k = 0; k < 6; k++) pu[k] = r6 ? t.PU[k * 6 + r5] : 0.0;
+				UNROLL for (int k = 0; k < 6; k++) pu[k] = sel0(r6, t.PU[k * 6 + r5]);
 				mm_rr<G, 6, N>(pu, jp, rows);
 			}
 			chain_append_g<G>(chain, rows, rank);
@@ -380,7 +386,7 @@ SAI2B_TASK_FN void mft_task_g(const DevParams& P, const DevTask& t, const Rob& r
 			mv_t<6, 6>(t.PU, jpT, x6);	// x6[c] = sum_k jpT[k] PU[k][c]
 			real wp[6], pu[6];
 			jacobi_rows<G, 6>(x6, wp, rank);
-			UNROLL for (int k = 0; k < 6; k++) pu[k] = r6 ? t.PU[r5 * 6 + k] : 0.0;	 // row r of PU
+			UNROLL for (int k = 0; k < 6; k++) pu[k] = sel0(r6, t.PU[r5 * 6 + k]);	 // row r of PU
 			mm_rr<G, 6, 6>(pu, wp, w6);
 		}
 		UNROLL for (int j = 0; j < 6; j++) {
@@ -681,10 +687,10 @@ SAI2B_TASK_FN void jt_task_g(const DevParams& P, const DevTask& t, const Rob& rb
 	GMARK(8, "jt_begin");
 	// Jp = S N_prec: its transpose column by column is local (S is batch-uniform); rows through the pad
 	real jpT[N], jp[N], srow[N];
-	UNROLL for (int l = 0; l < N; l++) srow[l] = rk ? t.S[rs * N + l] : 0.0;  // row r of S
+	UNROLL for (int l = 0; l < N; l++) srow[l] = sel0(rk, t.S[rs * N + l]);  // row r of S
 	if (first) {
 		const int rr = rN ? r : 0;
-		UNROLL for (int i = 0; i < N; i++) jpT[i] = rN ? t.S[i * N + rr] : 0.0;
+		UNROLL for (int i = 0; i < N; i++) jpT[i] = sel0(rN, t.S[i * N + rr]);
 		UNROLL for (int l = 0; l < N; l++) jp[l] = srow[l];
 	} else {
 		if (t.full_selection) {
@@ -838,8 +844,8 @@ DI void tick_robot(const DevParams& P, int b, real* pad, int commit_sh, int with
 	rb.pad = pad;
 	const bool rN = rb.r < N;
 	const int rs = rN ? rb.r : 0;
-	rb.q = rN ? ld(P.q, rs, B, b) : 0.0;
-	rb.dq = rN ? ld(P.dq, rs, B, b) : 0.0;
+	rb.q = sel0(rN, ld(P.q, rs, B, b));
+	rb.dq = sel0(rN, ld(P.dq, rs, B, b));
 	real g = 0;
 	GMARK(13, "model_begin");
 	{
