@@ -17,6 +17,8 @@
 
 #include <float.h>
 #include <math.h>
+
+#include "../include/sai2b_detmath.h"
 #include <string.h>
 
 #define EPS DBL_EPSILON
@@ -867,7 +869,7 @@ void otg_rot_to_angle_axis_vec(const double* R, double* out) {
 	}
 	double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
 	if (nrm != 0) {
-		const double angle = 2 * atan2(nrm, fabs(q[3]));
+		const double angle = 2 * sai2b_det_atan2_pos(nrm, fabs(q[3])); /* bit-reproducible: include/sai2b_detmath.h */
 		if (q[3] < 0) nrm = -nrm;
 		out[0] = angle * (q[0] / nrm);
 		out[1] = angle * (q[1] / nrm);
@@ -887,7 +889,8 @@ void otg_angle_axis_vec_to_rot(const double* v, double* R) {
 		return;
 	}
 	const double ax = v[0] / nrm, ay = v[1] / nrm, az = v[2] / nrm;
-	const double s = sin(nrm), c = cos(nrm);
+	double s, c;
+	sai2b_det_sincos(nrm, &s, &c); /* bit-reproducible: include/sai2b_detmath.h */
 	const double sx = s * ax, sy = s * ay, sz = s * az;
 	const double cx = (1 - c) * ax, cy = (1 - c) * ay, cz = (1 - c) * az;
 	double tmp;

@@ -20,6 +20,8 @@
 #pragma once
 #include <math.h>
 
+#include "../../include/sai2b_detmath.h"
+
 #ifndef SAI2B_HD
 #ifdef __HIPCC__
 #define SAI2B_HD __host__ __device__ __forceinline__
@@ -728,7 +730,11 @@ SAI2B_HD void rot_to_vec(const double* R, double* out) {
 	}
 	double nrm = sqrt(qx * qx + qy * qy + qz * qz);
 	if (nrm != 0) {
+		#ifdef SAI2B_OTG_LIBM_TRIG  // A/B builds only: the library's own functions, as before round 2
 		const double angle = 2 * atan2(nrm, fabs(qw));
+#else
+		const double angle = 2 * sai2b_det_atan2_pos(nrm, fabs(qw));
+#endif
 		if (qw < 0) nrm = -nrm;
 		out[0] = angle * (qx / nrm), out[1] = angle * (qy / nrm), out[2] = angle * (qz / nrm);
 	} else {
@@ -744,7 +750,12 @@ SAI2B_HD void vec_to_rot(double x, double y, double z, double* R) {
 		return;
 	}
 	const double ax = x / nrm, ay = y / nrm, az = z / nrm;
-	const double s = sin(nrm), c = cos(nrm);
+	double s, c;
+#ifdef SAI2B_OTG_LIBM_TRIG
+	s = sin(nrm), c = cos(nrm);
+#else
+	sai2b_det_sincos(nrm, &s, &c);
+#endif
 	const double sx = s * ax, sy = s * ay, sz = s * az;
 	const double cx = (1 - c) * ax, cy = (1 - c) * ay, cz = (1 - c) * az;
 	double tmp = cx * ay;

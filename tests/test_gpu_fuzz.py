@@ -287,6 +287,30 @@ def _event_run_setup(seed, introspection=None):
     return rng, name, tasks, otg, o, g
 
 
+# robots whose generators took the other (equally valid) planner branch than the oracle's, per seed: {seed: (robots, B)}.
+# SAI2B_FUZZ_SPLIT_LOG=<file> dumps it (exploratory sweeps); the bound is a fraction of the batch.
+_SPLIT_STATS = {}
+
+
+def _SPLIT_BOUND(B):
+    """Robots of a run that may sit on the other planner branch. Measured with the bit-reproducible sine / cosine /
+    arctangent of include/sai2b_detmath.h on both sides (round 2, 300 seeds): 295 seeds none, 4 seeds 1-5 robots,
+    one seed (59: new limits while every Cartesian generator is moving) 38 of 128 — the same picture as with the
+    libraries' own functions (4 seeds, 43 of 128 in seed 59), i.e. what is left comes from the generators' initial
+    poses (the forward kinematics of the two sides differ in the last bit), not from the trigonometry. The default
+    seeds allow 5 % of the batch (at least 6 robots); a wider sweep sets SAI2B_FUZZ_SPLIT_FRACTION."""
+    frac = os.environ.get("SAI2B_FUZZ_SPLIT_FRACTION")
+    return int(float(frac) * B) if frac else max(6, B // 20)
+
+
+def teardown_module(module):
+    path = os.environ.get("SAI2B_FUZZ_SPLIT_LOG")
+    if path and _SPLIT_STATS:
+        with open(path, "w") as f:
+            for seed, (n, B) in sorted(_SPLIT_STATS.items()):
+                f.write(f"{seed} {n} {B}\n")
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SAI2B_FUZZ_SEEDS", "32"))))
 def test_random_runtime_events_closed_loop(seed):
     """40 closed-loop periods with random run-time events applied to both sides in lock-step: new goals,
@@ -322,7 +346,8 @@ def test_random_runtime_events_closed_loop(seed):
         # (an event that makes a Cartesian generator re-plan in mid-motion — new limits, half of it re-initialised by
         # a force-space change — puts every moving robot on that threshold at once: 15-40 % of a batch have been
         # seen to take the other branch, those where libm and ocml differ in the last bit of a sine)
-        assert split.sum() <= 3 * B // 4, (seed, name, log[-6:], np.nonzero(split)[0])  # several such events in one run add up
+        _SPLIT_STATS[seed] = (int(split.sum()), B)
+        assert split.sum() <= _SPLIT_BOUND(B), (seed, name, log[-6:], np.nonzero(split)[0])  # several such events in one run add up
         e[split] = 0
         log[-1] = log[-1] + (float(f"{e.max():.1e}"),)
         ctx = (seed, name, otg, log[-6:])
