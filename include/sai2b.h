@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define SAI2B_DOF 7		  /* this build is specialised for 7-DOF serial revolute chains */
+#define SAI2B_MAX_DOF 8	  /* joints of the largest supported robot; the library holds builds for 4, 6, 7 and 8 */
+#define SAI2B_DOF 7		  /* the Panda's, the default of the helpers that take no robot (source compatibility) */
 #define SAI2B_MAX_TASKS 4 /* tasks in one controller hierarchy */
 #define SAI2B_SH_HISTORY 200 /* SingularityHandler.cpp:16 BUFFER_SIZE */
 
@@ -51,23 +52,34 @@ enum sai2b_status {
 	SAI2B_UNSUPPORTED = 3
 };
 
+/* reference: the joint types sai2-model reads from a URDF that the examples use (revolute / continuous,
+ * prismatic: examples/06-partial_joint_task/panda_arm_sliding_base.urdf) */
+enum sai2b_joint_type {
+	SAI2B_REVOLUTE = 0,
+	SAI2B_PRISMATIC = 1
+};
+
 /*
- * Rigid-body model of a fixed-base serial chain with SAI2B_DOF revolute joints about the local z
- * axis (the subset of sai2-model the path needs: reference call sites SURVEY §8(c)).
+ * Rigid-body model of a fixed-base serial chain with `dof` joints (4, 6, 7 or 8), each moving about (revolute)
+ * or along (prismatic) the z axis of its joint frame (the subset of sai2-model the path needs: reference call
+ * sites SURVEY §8(c)). A URDF joint with another <axis> is brought to this form by rotating its joint frame and
+ * re-expressing what hangs on it, which sai2b_model_from_urdf() does.
  * Joint i connects link i-1 (parent) to link i; link -1 is the world/base.
  * Fixed children (e.g. the Panda "end-effector" body, panda_arm.urdf:105-116,179-183) must be merged
  * into their parent's inertial parameters with sai2b_model_merge_fixed_body().
+ * Arrays are sized for SAI2B_MAX_DOF; entries >= dof are ignored.
  */
 typedef struct sai2b_robot_model {
-	int dof;									   /* must equal SAI2B_DOF */
-	double joint_xyz[SAI2B_DOF][3];				   /* URDF <origin xyz>, in parent link frame */
-	double joint_rpy[SAI2B_DOF][3];				   /* URDF <origin rpy>  (R = Rz(y) Ry(p) Rx(r)) */
-	double link_mass[SAI2B_DOF];				   /* child link of joint i */
-	double link_com[SAI2B_DOF][3];				   /* COM in link frame */
-	double link_inertia[SAI2B_DOF][6];			   /* ixx iyy izz ixy ixz iyz at the COM, link axes */
-	double q_lower[SAI2B_DOF], q_upper[SAI2B_DOF]; /* joint limits (SingularityHandler.cpp:43-51) */
-	double effort[SAI2B_DOF];
+	int dof;
+	double joint_xyz[SAI2B_MAX_DOF][3];				   /* URDF <origin xyz>, in parent link frame */
+	double joint_rpy[SAI2B_MAX_DOF][3];				   /* URDF <origin rpy>  (R = Rz(y) Ry(p) Rx(r)) */
+	double link_mass[SAI2B_MAX_DOF];				   /* child link of joint i */
+	double link_com[SAI2B_MAX_DOF][3];				   /* COM in link frame */
+	double link_inertia[SAI2B_MAX_DOF][6];			   /* ixx iyy izz ixy ixz iyz at the COM, link axes */
+	double q_lower[SAI2B_MAX_DOF], q_upper[SAI2B_MAX_DOF]; /* joint limits (SingularityHandler.cpp:43-51) */
+	double effort[SAI2B_MAX_DOF];
 	double gravity[3]; /* world gravity used by jointGravityVector (RobotController.cpp:71) */
+	int joint_type[SAI2B_MAX_DOF]; /* enum sai2b_joint_type */
 } sai2b_robot_model;
 
 /*
@@ -83,11 +95,11 @@ typedef struct sai2b_task_config {
 	double bie_threshold;
 
 	/* ---- JointTask (JointTask.cpp:14-89) ---- */
-	int task_dof;								  /* rows of the selection matrix (SAI2B_DOF if full) */
-	double joint_selection[SAI2B_DOF * SAI2B_DOF]; /* row-major task_dof x SAI2B_DOF */
-	double kp[SAI2B_DOF], kv[SAI2B_DOF], ki[SAI2B_DOF];
+	int task_dof;								  /* rows of the selection matrix (the robot's dof if full) */
+	double joint_selection[SAI2B_MAX_DOF * SAI2B_MAX_DOF]; /* row-major task_dof x robot_dof, packed (row stride = robot_dof) */
+	double kp[SAI2B_MAX_DOF], kv[SAI2B_MAX_DOF], ki[SAI2B_MAX_DOF];
 	int use_velocity_saturation; /* shared flag name for both task types */
-	double saturation_velocity[SAI2B_DOF];
+	double saturation_velocity[SAI2B_MAX_DOF];
 
 	/* ---- MotionForceTask (MotionForceTask.cpp:16-202) ---- */
 	int link;						/* 0-based moving link the compliant frame is attached to */
@@ -121,13 +133,16 @@ typedef struct sai2b_task_config {
 	 * to the control law is the OTG's next state instead of the goal. ---- */
 	int use_internal_otg;		   /* enableInternalOtgAccelerationLimited / disableInternalOtg */
 	int internal_otg_jerk_limited; /* must be 0: the jerk-limited generator is not implemented */
-	double otg_max_velocity[SAI2B_DOF], otg_max_acceleration[SAI2B_DOF]; /* JointTask, per task dof */
+	double otg_max_velocity[SAI2B_MAX_DOF], otg_max_acceleration[SAI2B_MAX_DOF]; /* JointTask, per task dof */
 	double otg_max_linear_velocity, otg_max_linear_acceleration;		 /* MotionForceTask */
 	double otg_max_angular_velocity, otg_max_angular_acceleration;
 
 	/* MotionForceTask::setPosControlGainsUnsafe / setOriControlGainsUnsafe (MotionForceTask.h:283,304;
 	 * MotionForceTask.cpp:630-649): nonzero skips the sign check of the motion gains */
 	int unsafe_motion_gains;
+
+	/* joints of the robot the task is for (filled by the sai2b_default_* helpers; 0 is read as SAI2B_DOF) */
+	int robot_dof;
 } sai2b_task_config;
 
 typedef struct sai2b_ctx sai2b_ctx;
@@ -136,7 +151,7 @@ typedef struct sai2b_ctx sai2b_ctx;
  * (host-only, no GPU needed) */
 
 /* Panda arm constants (examples/15-haptic_control_impedance_type/panda_arm.urdf:4-184), with the
- * fixed "end-effector" body merged into link 7. */
+ * fixed "end-effector" body merged into link 7 (dof = 7). */
 int sai2b_panda_model(sai2b_robot_model* model);
 
 /* Merge a fixed child body into link `link` (what RBDL does for URDF fixed joints). */
@@ -146,8 +161,9 @@ int sai2b_model_merge_fixed_body(sai2b_robot_model* model, int link, const doubl
 
 /* URDF ingestion (host-only). The reference loads robots from URDF through sai2-model (e.g.
  * examples/05-using_robot_controller/05-using_robot_controller.cpp:45-47 with panda_arm.urdf): this
- * reads the same files into a sai2b_robot_model. Scope: one serial chain of exactly SAI2B_DOF revolute
- * (or continuous) joints about their local z axis, any fixed joints (the bodies behind them are
+ * reads the same files into a sai2b_robot_model. Scope: one serial chain of 4, 6, 7 or 8 revolute / continuous /
+ * prismatic joints with any <axis> (panda_arm.urdf; examples/06-partial_joint_task/panda_arm_sliding_base.urdf;
+ * examples/11-planar_robot_controller/rrrrbot.urdf), any fixed joints (the bodies behind them are
  * merged into the link they hang on, as RBDL does), rotated <inertial> frames. `urdf` is a file name
  * (is_file != 0) or the XML text. `links` (may be NULL) receives, for every URDF link, the moving
  * link it is rigidly attached to (-1: the world) and its fixed pose there. */
@@ -169,10 +185,13 @@ int sai2b_urdf_resolve_frame(const sai2b_urdf_links* links, const char* link_nam
 							 double frame_pos[3], double frame_rot[9]);
 
 /* JointTask::JointTask + initialSetup defaults (JointTask.cpp:14-89, JointTask.h:31-45).
- * selection == NULL -> full joint task; else row-major task_dof x SAI2B_DOF, must be full row rank
+ * selection == NULL -> full joint task; else row-major task_dof x 7, must be full row rank
  * (JointTask.cpp:34-39). */
 int sai2b_default_joint_task(sai2b_task_config* cfg, const char* name, int task_dof,
 							 const double* selection);
+/* the same for a robot with `robot_dof` joints (selection: row-major task_dof x robot_dof) */
+int sai2b_default_joint_task_dof(sai2b_task_config* cfg, const char* name, int robot_dof, int task_dof,
+								 const double* selection);
 
 /* MotionForceTask::MotionForceTask + initialSetup defaults (MotionForceTask.cpp:16-202).
  * n_trans/n_rot < 0 -> full 6-DOF task (first ctor); otherwise the partial-task ctor with the given
@@ -181,6 +200,11 @@ int sai2b_default_motion_force_task(sai2b_task_config* cfg, const char* name, in
 									const double frame_pos[3], const double* frame_rot,
 									int n_trans, const double* dirs_trans, int n_rot,
 									const double* dirs_rot);
+/* the same for a robot with `robot_dof` joints (link < robot_dof) */
+int sai2b_default_motion_force_task_dof(sai2b_task_config* cfg, const char* name, int robot_dof, int link,
+										const double frame_pos[3], const double* frame_rot,
+										int n_trans, const double* dirs_trans, int n_rot,
+										const double* dirs_rot);
 
 /* RobotController ctor checks (RobotController.cpp:8-51): at least one task, same loop timestep,
  * unique names, nothing after a full joint task. Returns SAI2B_INVALID_ARGUMENT with `msg` filled. */

@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define OTG_MAX_DOF 7
+#ifndef OTG_MAX_DOF
+#define OTG_MAX_DOF 7 /* DoFs of the largest generator; the 8-joint build of the oracle sets 8 */
+#endif
 
 enum {
 	OTG_WORKING = 0,

@@ -17,8 +17,14 @@
 #include <omp.h>
 #endif
 
+/* joints of the robots this build of the oracle serves (oracle/Makefile builds one library per size: 4, 6, 7, 8) */
+#ifndef N7
 #define N7 SAI2B_DOF
-#define MAXD 7 /* largest matrix dimension anywhere on the path */
+#endif
+#define NN (N7 * N7) /* n x n */
+#define J6 (6 * N7)	 /* 6 x n */
+#define J3 (3 * N7)	 /* 3 x n */
+#define MAXD (N7 > 7 ? N7 : 7) /* largest matrix dimension anywhere on the path */
 #define POPC_RING 1024 /* window ring capacity (the reference queue is unbounded; same cap as the product) */
 
 static char g_err[512] = "";
@@ -395,7 +401,7 @@ int oracle_default_joint_task(sai2b_task_config* c, const char* name, int task_d
 		if (task_dof < 1 || task_dof > N7)
 			return fail("joint selection matrix size not consistent with robot dof in JointTask constructor");
 		/* JointTask.cpp:34-39: FullPivLU rank must equal the number of rows */
-		double U[49], s[7], V[49];
+		double U[NN], s[N7], V[NN];
 		oracle_svd(task_dof, N7, selection, U, s, V);
 		for (int i = 0; i < task_dof; i++)
 			if (!(s[i] > 1e-12 * s[0]) || s[0] == 0)
@@ -414,6 +420,7 @@ int oracle_default_joint_task(sai2b_task_config* c, const char* name, int task_d
 	c->use_velocity_saturation = 0;
 	c->use_internal_otg = 1; /* JointTask.h:38-39 */
 	c->internal_otg_jerk_limited = 0;
+	c->robot_dof = N7;
 	return 0;
 }
 
@@ -510,6 +517,7 @@ int oracle_default_motion_force_task(sai2b_task_config* c, const char* name, int
 	c->otg_max_linear_acceleration = 2.0;
 	c->otg_max_angular_velocity = M_PI / 3;
 	c->otg_max_angular_acceleration = 2.0 * M_PI;
+	c->robot_dof = N7;
 	return 0;
 }
 
@@ -519,13 +527,14 @@ int oracle_default_motion_force_task(sai2b_task_config* c, const char* name, int
 typedef struct {
 	double q[N7], dq[N7];
 	double Rl[N7][9], pl[N7][3]; /* link frames in world */
-	double M[49], Minv[49];
+	double M[NN], Minv[NN];
 	int model_valid;
+	const int* jtype; /* the ctx model's joint types (enum sai2b_joint_type) */
 } robot_t;
 
 typedef struct {
 	/* model */
-	double N_prec[49], Jp[49], R[49], M_partial[49], M_partial_mod[49], N[49];
+	double N_prec[NN], Jp[NN], R[NN], M_partial[NN], M_partial_mod[NN], N[NN];
 	int k; /* columns of the range basis, 0 = "zero range" */
 	/* goals / state */
 	double goal_q[N7], goal_dq[N7], goal_ddq[N7], integ[N7];
@@ -535,17 +544,17 @@ typedef struct {
 } jt_t;
 
 typedef struct {
-	double N_prec[49], J[42], Jp[42], N[49];
+	double N_prec[NN], J[J6], Jp[J6], N[NN];
 	/* goals */
 	double g_pos[3], g_rot[9], g_v[3], g_w[3], g_a[3], g_al[3], g_f[3], g_m[3];
 	double sens_f[3], sens_m[3];
 	double integ_pos[3], integ_ori[3], integ_f[3], integ_m[3];
 	/* SingularityHandler members */
-	double U[36], s[6], V[42];
+	double U[36], s[6], V[J6];
 	int ns, sc; /* columns of _task_range_ns / _task_range_s (0 = zero placeholder) */
-	double U_ns[36], J_ns[42], L_ns[36], Jbar_ns[42], N_ns[49];
-	double U_s[36], V_s[42], J_s[42], L_s[36];
-	double J_post[42], L_joint[36];
+	double U_ns[36], J_ns[J6], L_ns[36], Jbar_ns[J6], N_ns[NN];
+	double U_s[36], V_s[J6], J_s[J6], L_s[36];
+	double J_post[J6], L_joint[36];
 	double L_ns_mod[36], L_s_mod[36], L_joint_mod[36];
 	double alpha;
 	int n_types, types[6];
@@ -586,7 +595,12 @@ static void fk(const oracle_ctx* c, const double* q, double Rl[N7][9], double pl
 		for (int r = 0; r < 3; r++) pl[i][r] = pp[r] + Rp[3 * r] * x[0] + Rp[3 * r + 1] * x[1] + Rp[3 * r + 2] * x[2];
 		double RE[9], Rz[9] = {cos(q[i]), -sin(q[i]), 0, sin(q[i]), cos(q[i]), 0, 0, 0, 1};
 		mm(3, 3, 3, Rp, c->E[i], RE);
-		mm(3, 3, 3, RE, Rz, Rl[i]);
+		if (c->model.joint_type[i] == SAI2B_PRISMATIC) { /* slides along the joint frame's z by q */
+			memcpy(Rl[i], RE, sizeof(RE));
+			for (int r = 0; r < 3; r++) pl[i][r] += RE[3 * r + 2] * q[i];
+		} else {
+			mm(3, 3, 3, RE, Rz, Rl[i]);
+		}
 		memcpy(Rp, Rl[i], sizeof(Rp));
 		memcpy(pp, pl[i], sizeof(pp));
 	}
@@ -597,32 +611,33 @@ static void jacobian(const robot_t* r, int link, const double* pos_in_link, doub
 	for (int k = 0; k < 3; k++)
 		p[k] = r->pl[link][k] + r->Rl[link][3 * k] * pos_in_link[0] + r->Rl[link][3 * k + 1] * pos_in_link[1] +
 			   r->Rl[link][3 * k + 2] * pos_in_link[2];
-	for (int i = 0; i < 42; i++) J[i] = 0;
+	for (int i = 0; i < J6; i++) J[i] = 0;
 	for (int i = 0; i <= link; i++) {
 		double z[3] = {r->Rl[i][2], r->Rl[i][5], r->Rl[i][8]};
 		double d[3] = {p[0] - r->pl[i][0], p[1] - r->pl[i][1], p[2] - r->pl[i][2]};
 		double v[3];
 		cross3(z, d, v);
+		const int prismatic = r->jtype && r->jtype[i] == SAI2B_PRISMATIC; /* column (z, 0) instead of (z x d, z) */
 		for (int k = 0; k < 3; k++) {
-			J[k * N7 + i] = v[k];
-			J[(3 + k) * N7 + i] = z[k];
+			J[k * N7 + i] = prismatic ? z[k] : v[k];
+			J[(3 + k) * N7 + i] = prismatic ? 0.0 : z[k];
 		}
 	}
 }
 static void update_model(const oracle_ctx* c, robot_t* r) {
 	fk(c, r->q, r->Rl, r->pl);
 	/* M = sum_k m_k Jv_k^T Jv_k + Jw_k^T (R_k I_k R_k^T) Jw_k   (Jacobians at the link COMs) */
-	for (int i = 0; i < 49; i++) r->M[i] = 0;
+	for (int i = 0; i < NN; i++) r->M[i] = 0;
 	for (int k = 0; k < N7; k++) {
-		double J[42];
+		double J[J6];
 		jacobian(r, k, c->model.link_com[k], J);
 		const double* li = c->model.link_inertia[k];
 		double Il[9] = {li[0], li[3], li[4], li[3], li[1], li[5], li[4], li[5], li[2]};
 		double T[9], Iw[9];
 		mm(3, 3, 3, r->Rl[k], Il, T);
 		mm_nt(3, 3, 3, T, r->Rl[k], Iw);
-		double IJw[21];
-		mm(3, 3, N7, Iw, J + 21, IJw);
+		double IJw[J3];
+		mm(3, 3, N7, Iw, J + J3, IJw);
 		for (int a = 0; a < N7; a++)
 			for (int b = 0; b < N7; b++) {
 				double s = 0;
@@ -637,7 +652,7 @@ static void update_model(const oracle_ctx* c, robot_t* r) {
 static void gravity_vector(const oracle_ctx* c, const robot_t* r, double* g) {
 	for (int i = 0; i < N7; i++) g[i] = 0;
 	for (int k = 0; k < N7; k++) {
-		double J[42];
+		double J[J6];
 		jacobian(r, k, c->model.link_com[k], J);
 		for (int i = 0; i < N7; i++)
 			for (int d = 0; d < 3; d++) g[i] -= c->model.link_mass[k] * J[d * N7 + i] * c->model.gravity[d];
@@ -664,9 +679,16 @@ static void bias_vector(const oracle_ctx* c, const robot_t* r, int with_gravity,
 		for (int k = 0; k < 3; k++) a_i[k] = a_prev[k] + t1[k] + t3[k];
 		for (int k = 0; k < 3; k++) zq[k] = z[k] * r->dq[i];
 		cross3(w_prev, zq, t1);
+		const int prismatic = r->jtype && r->jtype[i] == SAI2B_PRISMATIC;
 		for (int k = 0; k < 3; k++) {
-			w[i][k] = w_prev[k] + zq[k];
-			al[i][k] = al_prev[k] + t1[k];
+			if (prismatic) { /* sliding frame: Coriolis acceleration 2 w x (z dq) of its origin, angular motion unchanged */
+				w[i][k] = w_prev[k];
+				al[i][k] = al_prev[k];
+				a_i[k] += 2 * t1[k];
+			} else {
+				w[i][k] = w_prev[k] + zq[k];
+				al[i][k] = al_prev[k] + t1[k];
+			}
 		}
 		double rc[3];
 		for (int k = 0; k < 3; k++) {
@@ -710,7 +732,8 @@ static void bias_vector(const oracle_ctx* c, const robot_t* r, int with_gravity,
 			cross3(d, f_next, t1);
 			for (int k = 0; k < 3; k++) n[k] += t1[k];
 		}
-		b[i] = r->Rl[i][2] * n[0] + r->Rl[i][5] * n[1] + r->Rl[i][8] * n[2];
+		const double* pr = (r->jtype && r->jtype[i] == SAI2B_PRISMATIC) ? f : n; /* prismatic: the force along the axis */
+		b[i] = r->Rl[i][2] * pr[0] + r->Rl[i][5] * pr[1] + r->Rl[i][8] * pr[2];
 		for (int k = 0; k < 3; k++) {
 			f_next[k] = f[k];
 			n_next[k] = n[k];
@@ -729,7 +752,7 @@ static void frame_pose(const sai2b_task_config* t, const double Rl[N7][9], const
 /* Sai2Model::operationalSpaceMatrices(J) as DEFINED in SURVEY App. D:
  * Lambda = (J M^-1 J^T)^-1, Jbar = M^-1 J^T Lambda, N = I - Jbar J */
 static void opspace(const robot_t* r, int m, const double* J, double* L, double* Jbar, double* N) {
-	double A[49], T[49], JT[49];
+	double A[NN], T[NN], JT[NN];
 	mm(m, N7, N7, J, r->Minv, T);
 	mm_nt(m, N7, m, T, J, A);
 	oracle_inverse(m, A, L);
@@ -737,11 +760,11 @@ static void opspace(const robot_t* r, int m, const double* J, double* L, double*
 	if (Jbar) memcpy(Jbar, JT, sizeof(double) * N7 * m);
 	mm(N7, m, N7, JT, J, T);
 	eye(N7, N);
-	for (int i = 0; i < 49; i++) N[i] -= T[i];
+	for (int i = 0; i < NN; i++) N[i] -= T[i];
 }
 static void bie_minv(const robot_t* r, double thr, double* MinvB) {
 	/* SingularityHandler.cpp:176-182, JointTask.cpp:254-260 */
-	double MB[49];
+	double MB[NN];
 	memcpy(MB, r->M, sizeof(MB));
 	for (int i = 0; i < N7; i++)
 		if (MB[i * N7 + i] < thr) MB[i * N7 + i] = thr;
@@ -749,7 +772,7 @@ static void bie_minv(const robot_t* r, double thr, double* MinvB) {
 }
 /* (J Minv J^T)^-1 for an m x 7 J */
 static void lambda_of(int m, const double* J, const double* Minv, double* L) {
-	double T[49], A[49];
+	double T[NN], A[NN];
 	mm(m, N7, N7, J, Minv, T);
 	mm_nt(m, N7, m, T, J, A);
 	oracle_inverse(m, A, L);
@@ -782,14 +805,14 @@ static void jt_construct(const sai2b_task_config* t, const robot_t* r, jt_t* s, 
 static void jt_update(const sai2b_task_config* t, const robot_t* r, jt_t* s, const double* N_prec) {
 	/* JointTask.cpp:218-283 */
 	int k0 = t->task_dof;
-	memcpy(s->N_prec, N_prec, sizeof(double) * 49);
+	memcpy(s->N_prec, N_prec, sizeof(double) * NN);
 	mm(k0, N7, N7, t->joint_selection, N_prec, s->Jp);
 	s->k = oracle_range_basis(k0, N7, s->Jp, 1e-3, s->R);
 	if (s->k == 0) { /* :234-239 */
 		eye(N7, s->N);
 		return;
 	}
-	double Jr[49];
+	double Jr[NN];
 	mm_tn(s->k, k0, N7, s->R, s->Jp, Jr);
 	opspace(r, s->k, Jr, s->M_partial, NULL, s->N);
 	switch (t->dynamic_decoupling_type) {
@@ -797,7 +820,7 @@ static void jt_update(const sai2b_task_config* t, const robot_t* r, jt_t* s, con
 			memcpy(s->M_partial_mod, s->M_partial, sizeof(double) * s->k * s->k);
 			break;
 		case SAI2B_BOUNDED_INERTIA_ESTIMATES: {
-			double MinvB[49];
+			double MinvB[NN];
 			bie_minv(r, t->bie_threshold, MinvB);
 			lambda_of(s->k, Jr, MinvB, s->M_partial_mod);
 			break;
@@ -1043,7 +1066,7 @@ static void sh_update(const oracle_ctx* c, const sai2b_task_config* t, const rob
 		for (int rr = 0; rr < N7; rr++)
 			for (int cc = 0; cc < s->sc; cc++) s->V_s[rr * s->sc + cc] = s->V[rr * 6 + split + cc];
 		mm_tn(s->sc, 6, N7, s->U_s, s->Jp, s->J_s);
-		double T[49], A[49];
+		double T[NN], A[NN];
 		mm(s->sc, N7, N7, s->J_s, r->Minv, T);
 		mm_nt(s->sc, N7, s->sc, T, s->J_s, A);
 		if (s->ns == 0)
@@ -1055,11 +1078,11 @@ static void sh_update(const oracle_ctx* c, const sai2b_task_config* t, const rob
 	 * explicitly: fully singular -> N = N_prec. */
 	int have_post = 0;
 	if (s->ns == 0) {
-		memcpy(s->N, N_prec, sizeof(double) * 49);
+		memcpy(s->N, N_prec, sizeof(double) * NN);
 	} else if (s->sc == 0 || !t->enforce_handling_strategy) {
-		memcpy(s->N, s->N_ns, sizeof(double) * 49);
+		memcpy(s->N, s->N_ns, sizeof(double) * NN);
 	} else {
-		double T[49], Np[49];
+		double T[NN], Np[NN];
 		mm(N7, N7, N7, s->N_ns, N_prec, T);
 		mm_tn(s->sc, N7, N7, s->V_s, T, s->J_post);
 		opspace(r, s->sc, s->J_post, s->L_joint, NULL, Np);
@@ -1074,7 +1097,7 @@ static void sh_update(const oracle_ctx* c, const sai2b_task_config* t, const rob
 			if (have_post) eye(s->sc, s->L_joint_mod);
 			break;
 		case SAI2B_BOUNDED_INERTIA_ESTIMATES: {
-			double MinvB[49];
+			double MinvB[NN];
 			bie_minv(r, t->bie_threshold, MinvB);
 			if (s->ns) lambda_of(s->ns, s->J_ns, MinvB, s->L_ns_mod);
 			if (s->sc) lambda_of(s->sc, s->J_s, MinvB, s->L_s_mod);
@@ -1091,8 +1114,8 @@ static void sh_update(const oracle_ctx* c, const sai2b_task_config* t, const rob
 static void mft_update(const oracle_ctx* c, const sai2b_task_config* t, const robot_t* r, mft_t* s,
 					   const double* N_prec) {
 	/* MotionForceTask.cpp:247-268 */
-	double Jw[42];
-	memcpy(s->N_prec, N_prec, sizeof(double) * 49);
+	double Jw[J6];
+	memcpy(s->N_prec, N_prec, sizeof(double) * NN);
 	jacobian(r, t->link, t->frame_pos, Jw);
 	mm(6, 6, N7, t->partial_projection, Jw, s->J);
 	mm(6, N7, N7, s->J, N_prec, s->Jp);
@@ -1208,14 +1231,14 @@ static void mv3(const double* A, const double* x, double* y) {
 static void mft_torques(const oracle_ctx* c, const sai2b_task_config* t, const robot_t* r, mft_t* s,
 						otg_cartesian* o, double* tau) {
 	/* MotionForceTask.cpp:278-509 */
-	double Jw[42], x[3], R[9], v[3], w[3];
+	double Jw[J6], x[3], R[9], v[3], w[3];
 	for (int i = 0; i < N7; i++) tau[i] = 0;
 	jacobian(r, t->link, t->frame_pos, Jw);
 	mm(6, 6, N7, t->partial_projection, Jw, s->J);
 	mm(6, N7, N7, s->J, s->N_prec, s->Jp);
 	frame_pose(t, r->Rl, r->pl, x, R);
 	mm(3, N7, 1, s->J, r->dq, v);
-	mm(3, N7, 1, s->J + 21, r->dq, w);
+	mm(3, N7, 1, s->J + J3, r->dq, w);
 	memcpy(s->cur_pos, x, sizeof(s->cur_pos));
 	memcpy(s->cur_rot, R, sizeof(s->cur_rot));
 	if (t->pos_range + t->ori_range == 0) return;
@@ -1403,6 +1426,7 @@ oracle_ctx* oracle_create(const sai2b_robot_model* model, const sai2b_task_confi
 	c->model = *model;
 	for (int i = 0; i < N7; i++) rpy_to_rot(model->joint_rpy[i], c->E[i]);
 	c->robots = (robot_t*)calloc(batch, sizeof(robot_t));
+	for (int b = 0; b < batch; b++) c->robots[b].jtype = c->model.joint_type;
 	for (int i = 0; i < n_tasks; i++) {
 		c->cfg[i] = tasks[i];
 		if (tasks[i].type == SAI2B_JOINT_TASK) {
@@ -1576,7 +1600,7 @@ static void robot_update_models(oracle_ctx* c, int b) {
 	/* RobotController.cpp:53-60 */
 	robot_t* r = &c->robots[b];
 	ensure_model(c, b);
-	double N_prec[49], T[49];
+	double N_prec[NN], T[NN];
 	eye(N7, N_prec);
 	for (int i = 0; i < c->T; i++) {
 		const double* N;
@@ -1653,9 +1677,9 @@ int oracle_task_update_model(oracle_ctx* c, int task, const double* N_prec) {
 	if (task < 0 || task >= c->T) return fail("bad task");
 #pragma omp parallel for num_threads(c->threads) schedule(static)
 	for (int b = 0; b < c->B; b++) {
-		double Np[49];
+		double Np[NN];
 		if (N_prec)
-			for (int i = 0; i < 49; i++) Np[i] = N_prec[i * c->B + b];
+			for (int i = 0; i < NN; i++) Np[i] = N_prec[i * c->B + b];
 		else
 			eye(N7, Np);
 		ensure_model(c, b);
@@ -1709,9 +1733,9 @@ int oracle_task_get_nullspaces(oracle_ctx* c, int task, double* N, double* N_pre
 	for (int b = 0; b < c->B; b++) {
 		const double* n = c->jt[task] ? c->jt[task][b].N : c->mft[task][b].N;
 		const double* np = c->jt[task] ? c->jt[task][b].N_prec : c->mft[task][b].N_prec;
-		double T[49];
+		double T[NN];
 		mm(N7, N7, N7, n, np, T);
-		for (int i = 0; i < 49; i++) {
+		for (int i = 0; i < NN; i++) {
 			if (N) N[i * c->B + b] = n[i];
 			if (N_prec) N_prec[i * c->B + b] = np[i];
 			if (N_total) N_total[i * c->B + b] = T[i];
@@ -1724,12 +1748,12 @@ int oracle_task_get_nullspaces(oracle_ctx* c, int task, double* N, double* N_pre
 int oracle_get_task_nullspace(oracle_ctx* c, int task, double* out) {
 	if (task < 0 || task >= c->T) return fail("bad task");
 	for (int b = 0; b < c->B; b++) {
-		double T[49];
+		double T[NN];
 		if (c->jt[task])
 			mm(N7, N7, N7, c->jt[task][b].N, c->jt[task][b].N_prec, T);
 		else
 			mm(N7, N7, N7, c->mft[task][b].N, c->mft[task][b].N_prec, T);
-		for (int i = 0; i < 49; i++) out[i * c->B + b] = T[i];
+		for (int i = 0; i < NN; i++) out[i * c->B + b] = T[i];
 	}
 	return 0;
 }
@@ -1755,14 +1779,14 @@ int oracle_get_model(oracle_ctx* c, int task, double* M, double* J, double* pos,
 		ensure_model(c, b);
 		const robot_t* r = &c->robots[b];
 		if (M)
-			for (int i = 0; i < 49; i++) M[i * c->B + b] = r->M[i];
+			for (int i = 0; i < NN; i++) M[i * c->B + b] = r->M[i];
 		if (J || pos || rot) {
 			if (task < 0 || task >= c->T || !c->mft[task]) return fail("not a MotionForceTask");
-			double Jw[42], x[3], R[9];
+			double Jw[J6], x[3], R[9];
 			jacobian(r, c->cfg[task].link, c->cfg[task].frame_pos, Jw);
 			frame_pose(&c->cfg[task], r->Rl, r->pl, x, R);
 			if (J)
-				for (int i = 0; i < 42; i++) J[i * c->B + b] = Jw[i];
+				for (int i = 0; i < J6; i++) J[i * c->B + b] = Jw[i];
 			if (pos)
 				for (int i = 0; i < 3; i++) pos[i * c->B + b] = x[i];
 			if (rot)
@@ -1774,7 +1798,7 @@ int oracle_get_model(oracle_ctx* c, int task, double* M, double* J, double* pos,
 int oracle_get_minv(oracle_ctx* c, double* out) {
 	for (int b = 0; b < c->B; b++) {
 		ensure_model(c, b);
-		for (int i = 0; i < 49; i++) out[i * c->B + b] = c->robots[b].Minv[i];
+		for (int i = 0; i < NN; i++) out[i * c->B + b] = c->robots[b].Minv[i];
 	}
 	return 0;
 }
@@ -1788,7 +1812,7 @@ int oracle_get_gravity(oracle_ctx* c, double* out) {
 	return 0;
 }
 static void embed(int rows, int cols, const double* U, const double* L, double* out) { /* U L U^T */
-	double T[49];
+	double T[NN];
 	mm(rows, cols, cols, U, L, T);
 	mm_nt(rows, cols, rows, T, U, out);
 }
@@ -1985,7 +2009,7 @@ int oracle_get_jt_inertia(oracle_ctx* c, int task, double* Mp, double* Mpm) {
 	int k0 = c->cfg[task].task_dof;
 	for (int b = 0; b < c->B; b++) {
 		const jt_t* s = &c->jt[task][b];
-		double A[49] = {0}, Bm[49] = {0};
+		double A[NN] = {0}, Bm[NN] = {0};
 		if (s->k) {
 			embed(k0, s->k, s->R, s->M_partial, A);
 			embed(k0, s->k, s->R, s->M_partial_mod, Bm);

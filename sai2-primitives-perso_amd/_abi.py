@@ -7,7 +7,8 @@ fails loudly when it has not been built — there is no CPU fallback.
 import ctypes as C
 import os
 
-DOF = 7
+DOF = 7  # the Panda's: default of the helpers that take no robot
+MAX_DOF = 8
 MAX_TASKS = 4
 SH_HISTORY = 200
 
@@ -29,15 +30,16 @@ class RobotModel(C.Structure):
 
     _fields_ = [
         ("dof", _i),
-        ("joint_xyz", (_d * 3) * DOF),
-        ("joint_rpy", (_d * 3) * DOF),
-        ("link_mass", _d * DOF),
-        ("link_com", (_d * 3) * DOF),
-        ("link_inertia", (_d * 6) * DOF),
-        ("q_lower", _d * DOF),
-        ("q_upper", _d * DOF),
-        ("effort", _d * DOF),
+        ("joint_xyz", (_d * 3) * MAX_DOF),
+        ("joint_rpy", (_d * 3) * MAX_DOF),
+        ("link_mass", _d * MAX_DOF),
+        ("link_com", (_d * 3) * MAX_DOF),
+        ("link_inertia", (_d * 6) * MAX_DOF),
+        ("q_lower", _d * MAX_DOF),
+        ("q_upper", _d * MAX_DOF),
+        ("effort", _d * MAX_DOF),
         ("gravity", _d * 3),
+        ("joint_type", _i * MAX_DOF),
     ]
 
 
@@ -52,12 +54,12 @@ class TaskConfig(C.Structure):
         ("bie_threshold", _d),
         # JointTask
         ("task_dof", _i),
-        ("joint_selection", _d * (DOF * DOF)),
-        ("kp", _d * DOF),
-        ("kv", _d * DOF),
-        ("ki", _d * DOF),
+        ("joint_selection", _d * (MAX_DOF * MAX_DOF)),
+        ("kp", _d * MAX_DOF),
+        ("kv", _d * MAX_DOF),
+        ("ki", _d * MAX_DOF),
         ("use_velocity_saturation", _i),
-        ("saturation_velocity", _d * DOF),
+        ("saturation_velocity", _d * MAX_DOF),
         # MotionForceTask
         ("link", _i),
         ("frame_pos", _d * 3),
@@ -110,13 +112,14 @@ class TaskConfig(C.Structure):
         # internal OTG
         ("use_internal_otg", _i),
         ("internal_otg_jerk_limited", _i),
-        ("otg_max_velocity", _d * DOF),
-        ("otg_max_acceleration", _d * DOF),
+        ("otg_max_velocity", _d * MAX_DOF),
+        ("otg_max_acceleration", _d * MAX_DOF),
         ("otg_max_linear_velocity", _d),
         ("otg_max_linear_acceleration", _d),
         ("otg_max_angular_velocity", _d),
         ("otg_max_angular_acceleration", _d),
         ("unsafe_motion_gains", _i),
+        ("robot_dof", _i),
     ]
 
 
@@ -170,7 +173,9 @@ EXPORTS = [
     "sai2b_model_from_urdf",
     "sai2b_urdf_resolve_frame",
     "sai2b_default_joint_task",
+    "sai2b_default_joint_task_dof",
     "sai2b_default_motion_force_task",
+    "sai2b_default_motion_force_task_dof",
     "sai2b_validate_tasks",
     "sai2b_create",
     "sai2b_destroy",
@@ -251,6 +256,8 @@ def load_library():
     lib.sai2b_model_from_urdf.argtypes = [C.c_char_p, _i, P(RobotModel), P(UrdfLinks)]
     lib.sai2b_urdf_resolve_frame.argtypes = [P(UrdfLinks), C.c_char_p, dp, dp, P(_i), dp, dp]
     lib.sai2b_default_joint_task.argtypes = [P(TaskConfig), C.c_char_p, _i, dp]
+    lib.sai2b_default_joint_task_dof.argtypes = [P(TaskConfig), C.c_char_p, _i, _i, dp]
+    lib.sai2b_default_motion_force_task_dof.argtypes = [P(TaskConfig), C.c_char_p, _i, _i, dp, dp, _i, dp, _i, dp]
     lib.sai2b_default_motion_force_task.argtypes = [P(TaskConfig), C.c_char_p, _i, dp, dp, _i, dp, _i, dp]
     lib.sai2b_validate_tasks.argtypes = [P(TaskConfig), _i, C.c_char_p, _i]
     lib.sai2b_create.argtypes = [P(RobotModel), P(TaskConfig), _i, _i, _i]

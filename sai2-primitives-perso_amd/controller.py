@@ -59,7 +59,7 @@ def resolve_link_frame(links, link_name, pos_in_link=(0.0, 0.0, 0.0), rot_in_lin
     return link.value, fp, fr.reshape(3, 3)
 
 
-def joint_task_config(name=None, selection=None, internal_otg=False):
+def joint_task_config(name=None, selection=None, internal_otg=False, robot_dof=DOF):
     """sai2b_default_joint_task(): JointTask ctor + defaults (JointTask.cpp:14-89).
     The library default is the reference's: internal OTG on (JointTask.h:38). This helper turns it
     off unless internal_otg=True, the way the reference's examples call disableInternalOtg() after
@@ -67,9 +67,10 @@ def joint_task_config(name=None, selection=None, internal_otg=False):
     lib = _abi.load_library()
     c = TaskConfig()
     sel = None if selection is None else np.ascontiguousarray(selection, dtype=np.float64)
-    if sel is not None and (sel.ndim != 2 or sel.shape[1] != DOF):
+    if sel is not None and (sel.ndim != 2 or sel.shape[1] != robot_dof):
         raise ValueError("joint selection matrix size not consistent with robot dof in JointTask constructor\n")
-    rc = lib.sai2b_default_joint_task(C.byref(c), name.encode() if name else None, 0 if sel is None else sel.shape[0], _dp(sel))
+    rc = lib.sai2b_default_joint_task_dof(C.byref(c), name.encode() if name else None, int(robot_dof), 0 if sel is None else sel.shape[0],
+                                          _dp(sel))
     _check(lib, None, rc)
     if not internal_otg:
         c.use_internal_otg = 0
@@ -77,7 +78,7 @@ def joint_task_config(name=None, selection=None, internal_otg=False):
 
 
 def motion_force_task_config(name=None, link=EE_LINK, frame_pos=EE_FRAME_POS, frame_rot=None, partial=None,
-                             internal_otg=False):
+                             internal_otg=False, robot_dof=DOF):
     """sai2b_default_motion_force_task(): MotionForceTask ctors + defaults (MotionForceTask.cpp:16-202).
     partial = (translation directions [n,3], rotation directions [m,3]) selects the partial-task ctor.
     internal_otg: see joint_task_config (library default on, this helper's default off)."""
@@ -91,8 +92,8 @@ def motion_force_task_config(name=None, link=EE_LINK, frame_pos=EE_FRAME_POS, fr
         dt = np.ascontiguousarray(partial[0], dtype=np.float64).reshape(-1, 3)
         dr = np.ascontiguousarray(partial[1], dtype=np.float64).reshape(-1, 3)
         nt, nr = dt.shape[0], dr.shape[0]
-    rc = lib.sai2b_default_motion_force_task(
-        C.byref(c), name.encode() if name else None, link, _dp(fp), _dp(fr),
+    rc = lib.sai2b_default_motion_force_task_dof(
+        C.byref(c), name.encode() if name else None, int(robot_dof), link, _dp(fp), _dp(fr),
         nt, _dp(dt) if nt and nt > 0 else None, nr, _dp(dr) if nr and nr > 0 else None,
     )
     _check(lib, None, rc)
@@ -118,6 +119,7 @@ class Controller:
     def __init__(self, model, tasks, batch, device=0, introspection=False):
         self.lib = _abi.load_library()
         self.B = int(batch)
+        self.dof = int(model.dof)  # joints of the robot: the library routes to its build for that size
         self.tasks = list(tasks)
         arr = (TaskConfig * len(self.tasks))(*self.tasks)
         self.h = self.lib.sai2b_create(C.byref(model), arr, len(self.tasks), self.B, int(device))
@@ -185,8 +187,8 @@ class Controller:
 
     # -- inputs
     def set_state(self, q=None, dq=None):
-        pq, kq = self._in(q, DOF)
-        pd, kd = self._in(dq, DOF)
+        pq, kq = self._in(q, self.dof)
+        pd, kd = self._in(dq, self.dof)
         self._rc(self.lib.sai2b_set_state(self.h, pq, pd, self._dev(q, dq)))
 
     def set_mft_goals(self, task, pos=None, rot=None, v=None, w=None, a=None, alpha=None):
@@ -228,8 +230,8 @@ class Controller:
 
     def _torques(self, call, out):
         if out is None:
-            out = np.empty((DOF, self.B))
-        p, keep = self._in(out, DOF)
+            out = np.empty((self.dof, self.B))
+        p, keep = self._in(out, self.dof)
         if not hasattr(out, "data_ptr") and keep is not out:
             raise ValueError("out must be a C-contiguous float64 array")
         self._rc(call(p, self._dev(out)))
@@ -238,15 +240,15 @@ class Controller:
     # -- task-level plugin interface (TemplateTask.h:42-88): one task driven on its own
     def task_update_model(self, task, N_prec=None):
         """TemplateTask::updateTaskModel(N_prec); N_prec [n*n][B] (numpy or torch CUDA), None = identity"""
-        p, _ = self._in(N_prec, DOF * DOF)
+        p, _ = self._in(N_prec, self.dof * self.dof)
         self._rc(self.lib.sai2b_task_update_model(self.h, task, p, self._dev(N_prec)))
 
     def task_compute_torques(self, task, tau_prec=None, out=None):
         """TemplateTask::computeTorques() / computeTorques(tau_prec): the task's own torques [n][B]"""
-        p, _ = self._in(tau_prec, DOF)
+        p, _ = self._in(tau_prec, self.dof)
         if out is None:
-            out = np.empty((DOF, self.B))
-        po, keep = self._in(out, DOF)
+            out = np.empty((self.dof, self.B))
+        po, keep = self._in(out, self.dof)
         if tau_prec is not None and self._dev(tau_prec) != self._dev(out):
             raise ValueError("tau_prec and out must both be host arrays or both device tensors")
         self._rc(self.lib.sai2b_task_compute_torques(self.h, task, p, po, self._dev(out)))
@@ -257,7 +259,7 @@ class Controller:
 
     def task_nullspaces(self, task):
         """(N, N_prec, N * N_prec) of the task's last model update, [n*n][B] each"""
-        out = [np.empty((DOF * DOF, self.B)) for _ in range(3)]
+        out = [np.empty((self.dof * self.dof, self.B)) for _ in range(3)]
         self._rc(self.lib.sai2b_task_get_nullspaces(self.h, task, *[C.c_void_p(x.ctypes.data) for x in out]))
         return tuple(out)
 
@@ -273,7 +275,7 @@ class Controller:
         return tuple(out)
 
     def set_mft_type1_posture(self, task, q_des):
-        p, _ = self._in(q_des, DOF)
+        p, _ = self._in(q_des, self.dof)
         self._rc(self.lib.sai2b_set_mft_type1_posture(self.h, task, p, self._dev(q_des)))
 
     def get_singularity_types_count(self, task):
@@ -311,12 +313,12 @@ class Controller:
 
     # -- introspection of the last tick
     def get_task_nullspace(self, task):
-        out = np.empty((DOF * DOF, self.B))
+        out = np.empty((self.dof * self.dof, self.B))
         self._rc(self.lib.sai2b_get_task_nullspace(self.h, task, C.c_void_p(out.ctypes.data)))
         return out
 
     def get_task_torques(self, task):
-        out = np.empty((DOF, self.B))
+        out = np.empty((self.dof, self.B))
         self._rc(self.lib.sai2b_get_task_torques(self.h, task, C.c_void_p(out.ctypes.data)))
         return out
 
@@ -359,16 +361,16 @@ class Controller:
     def sim_step(self, tau=None, dt=0.001, substeps=1, with_gravity=False):
         """one control period of rigid-body dynamics under `tau` (None = the last computed torques; numpy
         [7][B] or a torch CUDA tensor), state updated in place on the device"""
-        p, _ = self._in(tau, DOF)
+        p, _ = self._in(tau, self.dof)
         self._rc(self.lib.sai2b_sim_step(self.h, p, self._dev(tau), float(dt), int(substeps), int(with_gravity)))
 
     def get_state(self):
-        q, dq = np.empty((DOF, self.B)), np.empty((DOF, self.B))
+        q, dq = np.empty((self.dof, self.B)), np.empty((self.dof, self.B))
         self._rc(self.lib.sai2b_get_state(self.h, C.c_void_p(q.ctypes.data), C.c_void_p(dq.ctypes.data)))
         return q, dq
 
     def get_bias(self, with_gravity=False):
-        out = np.empty((DOF, self.B))
+        out = np.empty((self.dof, self.B))
         self._rc(self.lib.sai2b_get_bias(self.h, int(with_gravity), C.c_void_p(out.ctypes.data)))
         return out
 
@@ -393,11 +395,11 @@ class Controller:
         return a, b
 
     def get_model(self, task=-1):
-        M = np.empty((DOF * DOF, self.B))
+        M = np.empty((self.dof * self.dof, self.B))
         if task < 0:
             self._rc(self.lib.sai2b_get_model(self.h, -1, C.c_void_p(M.ctypes.data), None, None, None))
             return M
-        J, x, R = np.empty((6 * DOF, self.B)), np.empty((3, self.B)), np.empty((9, self.B))
+        J, x, R = np.empty((6 * self.dof, self.B)), np.empty((3, self.B)), np.empty((9, self.B))
         self._rc(self.lib.sai2b_get_model(self.h, task, *[C.c_void_p(a.ctypes.data) for a in (M, J, x, R)]))
         return M, J, x, R
 
@@ -417,13 +419,13 @@ class BatchedRobotModel:
         if urdf_file is not None:  # Sai2Model::Sai2Model(urdf_file) (examples/05-...cpp:96-97)
             model, self.links = model_from_urdf(urdf_file)
         self.model = model if model is not None else panda_model()
-        self._q = np.zeros((DOF, self.batch))
-        self._dq = np.zeros((DOF, self.batch))
+        self._q = np.zeros((self.model.dof, self.batch))
+        self._dq = np.zeros((self.model.dof, self.batch))
         self._controller = None
         self._standalone = []  # tasks driven on their own (TemplateTask-level calls): each has its 1-task context
 
     def dof(self):
-        return DOF
+        return int(self.model.dof)
 
     def setQ(self, q):
         self._q = q
@@ -549,12 +551,12 @@ class JointTask(_TaskBase):
     """reference src/tasks/JointTask.h:56-75 (ctors), :137-179 (goals), :234-259 (gains)"""
 
     def __init__(self, robot, joint_selection_matrix=None, task_name="joint_task", loop_timestep=0.001):
-        cfg = joint_task_config(task_name, joint_selection_matrix, internal_otg=True)  # JointTask.h:38
+        cfg = joint_task_config(task_name, joint_selection_matrix, internal_otg=True, robot_dof=robot.dof())  # JointTask.h:38
         cfg.loop_timestep = loop_timestep
         super().__init__(robot, cfg)
 
     def isFullJointTask(self):
-        return self._cfg.task_dof == DOF
+        return self._cfg.task_dof == self._robot.dof()
 
     def setGoalPosition(self, q):
         self._goal("q", q, self._cfg.task_dof)
@@ -601,12 +603,12 @@ class JointTask(_TaskBase):
     def getCurrentPosition(self):
         """S q (JointTask.h:130), from the controller's state buffer"""
         rc, idx = self._require_owner()
-        S = np.array(self._cfg.joint_selection[: self._cfg.task_dof * DOF]).reshape(self._cfg.task_dof, DOF)
+        S = np.array(self._cfg.joint_selection[: self._cfg.task_dof * self._robot.dof()]).reshape(self._cfg.task_dof, self._robot.dof())
         return S @ rc._ctrl.get_state()[0]
 
     def getCurrentVelocity(self):
         rc, idx = self._require_owner()
-        S = np.array(self._cfg.joint_selection[: self._cfg.task_dof * DOF]).reshape(self._cfg.task_dof, DOF)
+        S = np.array(self._cfg.joint_selection[: self._cfg.task_dof * self._robot.dof()]).reshape(self._cfg.task_dof, self._robot.dof())
         return S @ rc._ctrl.get_state()[1]
 
     def getGains(self):
@@ -687,7 +689,7 @@ class MotionForceTask(_TaskBase):
                 raise ValueError("link names need a robot model built from a URDF file")
             link, compliant_frame_pos, compliant_frame_rot = resolve_link_frame(robot.links, link, compliant_frame_pos, compliant_frame_rot)
         cfg = motion_force_task_config(task_name, link, compliant_frame_pos, compliant_frame_rot, partial,
-                                       internal_otg=True)  # MotionForceTask.h:67
+                                       internal_otg=True, robot_dof=robot.dof())  # MotionForceTask.h:67
         cfg.parametrization_in_compliant_frame = int(is_force_motion_parametrization_in_compliant_frame)
         cfg.loop_timestep = loop_timestep
         super().__init__(robot, cfg)

@@ -223,10 +223,13 @@ DI void fk(const MD& md, const real* q, Frames& F) {
 		}
 		real s, c;
 		sincos_joint(q[i], &s, &c);
+		const bool pris = md.jtype[i] != 0;	 // prismatic: the frame slides along its z instead of turning about it
+		if (pris) s = 0, c = 1;
 		UNROLL for (int k = 0; k < 3; k++) {
 			F.R[i][3 * k + 0] = fma(c, RE[3 * k], s * RE[3 * k + 1]);
 			F.R[i][3 * k + 1] = fma(c, RE[3 * k + 1], -s * RE[3 * k]);
 			F.R[i][3 * k + 2] = RE[3 * k + 2];
+			if (pris) F.p[i][k] = fma(q[i], RE[3 * k + 2], F.p[i][k]);
 		}
 		UNROLL for (int k = 0; k < 9; k++) Rp[k] = F.R[i][k];
 		UNROLL for (int k = 0; k < 3; k++) pp[k] = F.p[i][k];
@@ -247,16 +250,17 @@ DI void frame_pose(const DevTask& t, const Frames& F, real* x, real* R) {
 		x[k] = fma(Rl[3 * k], t.frame_pos[0], fma(Rl[3 * k + 1], t.frame_pos[1], fma(Rl[3 * k + 2], t.frame_pos[2], pl[k])));
 	mm<3, 3, 3>(Rl, t.frame_rot, R);
 }
-// Sai2Model::JWorldFrame(link, pos): 6 x 7, linear rows first
-DI void jacobian(const DevTask& t, const Frames& F, const real* x, real* J) {
+// Sai2Model::JWorldFrame(link, pos): 6 x n, linear rows first; a prismatic joint's column is (z, 0)
+template <class MD>
+DI void jacobian(const MD& md, const DevTask& t, const Frames& F, const real* x, real* J) {
 	UNROLL for (int i = 0; i < N; i++) {
 		real z[3] = {F.R[i][2], F.R[i][5], F.R[i][8]};
 		real d[3] = {x[0] - F.p[i][0], x[1] - F.p[i][1], x[2] - F.p[i][2]}, v[3];
 		cross3(z, d, v);
-		const bool on = i <= t.link;
+		const bool on = i <= t.link, pris = md.jtype[i] != 0;
 		UNROLL for (int k = 0; k < 3; k++) {
-			J[k * N + i] = on ? v[k] : 0.0;
-			J[(3 + k) * N + i] = on ? z[k] : 0.0;
+			J[k * N + i] = on ? (pris ? z[k] : v[k]) : 0.0;
+			J[(3 + k) * N + i] = (on && !pris) ? z[k] : 0.0;
 		}
 	}
 }
@@ -264,12 +268,16 @@ DI void jacobian(const DevTask& t, const Frames& F, const real* x, real* J) {
 // about the world origin (what Sai2Model::updateModel() obtains from RBDL's CRBA).
 template <class MD>
 DI void mass_matrix(const MD& md, const Frames& F, real* M) {
-	real z[N][3], v[N][3];	// joint twists (z_i, p_i x z_i)
+	real z[N][3], v[N][3];	// joint twists about the world origin: (z_i, p_i x z_i) revolute, (0, z_i) prismatic
 	UNROLL for (int i = 0; i < N; i++) {
-		z[i][0] = F.R[i][2];
-		z[i][1] = F.R[i][5];
-		z[i][2] = F.R[i][8];
-		cross3(F.p[i], z[i], v[i]);
+		const real ax[3] = {F.R[i][2], F.R[i][5], F.R[i][8]};
+		const bool pris = md.jtype[i] != 0;
+		real pxz[3];
+		cross3(F.p[i], ax, pxz);
+		UNROLL for (int k = 0; k < 3; k++) {
+			z[i][k] = pris ? 0.0 : ax[k];
+			v[i][k] = pris ? ax[k] : pxz[k];
+		}
 	}
 	real mt = 0, h[3] = {0, 0, 0}, IO[6] = {0, 0, 0, 0, 0, 0};	// xx yy zz xy xz yz
 	UNROLL for (int k = N - 1; k >= 0; k--) {
@@ -319,6 +327,9 @@ DI void gravity_vector(const MD& md, const Frames& F, real* g) {
 		real d[3] = {h[0] - mt * F.p[k][0], h[1] - mt * F.p[k][1], h[2] - mt * F.p[k][2]};
 		real zk[3] = {R[2], R[5], R[8]}, x[3];
 		cross3(zk, d, x);
+		if (md.jtype[k] != 0) {	 // prismatic: the weight of everything outboard along the axis
+			UNROLL for (int a = 0; a < 3; a++) x[a] = mt * zk[a];
+		}
 		g[k] = -(x[0] * md.gravity[0] + x[1] * md.gravity[1] + x[2] * md.gravity[2]);
 	}
 }
@@ -731,7 +742,7 @@ DI void mft_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B
 	fk(P.model, rc.q, F);
 	real x[3], R[9], Jw[6 * N], J[6 * N], Jp[6 * N];
 	frame_pose(t, F, x, R);
-	jacobian(t, F, x, Jw);
+	jacobian(P.model, t, F, x, Jw);
 	if (t.full_projection) {
 		UNROLL for (int i = 0; i < 6 * N; i++) J[i] = Jw[i];
 	} else {

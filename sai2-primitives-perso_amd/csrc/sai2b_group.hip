@@ -19,7 +19,7 @@ __global__ __launch_bounds__(64) SAI2B_GROUP_OCC void tick_group_kernel(const De
 														   int do_torque, const int* __restrict__ fb_count,
 														   const int* __restrict__ fb_list) {
 	constexpr int GPB = 64 / G;	 // robots per workgroup (one wavefront)
-	__shared__ real pads[GPB][N * (N | 1)];
+	__shared__ real pads[GPB][grp::PAD_DOUBLES];
 	const DevParams& P = *Pp;
 	const int gi = grp::group<G>();
 	if (fb_count) {

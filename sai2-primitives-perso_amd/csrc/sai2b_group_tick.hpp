@@ -45,6 +45,10 @@ __device__ int g_stamp_n;
 #define GMARK(id, name) do { } while (0)
 #endif
 
+// LDS scratch of a group: the largest transposition is max(N, 6) square, rows padded to an odd length
+constexpr int PAD_N = N > 6 ? N : 6;
+constexpr int PAD_DOUBLES = PAD_N * (PAD_N | 1);
+
 // per-lane view of one robot
 struct Rob {
 	int r;			 // lane within the group
@@ -52,7 +56,7 @@ struct Rob {
 	real q, dq;		 // this lane's joint (0 beyond the last joint)
 	real FR[9], Fp[3];	// world frame of this lane's link
 	real minv[N], minvB[N];	 // row r of M^-1 and of the bounded-inertia M_BIE^-1
-	real* pad;		 // the group's LDS scratch (N * (N | 1) doubles)
+	real* pad;		 // the group's LDS scratch (PAD_DOUBLES)
 };
 
 // ------------------------------------------------------------------ forward kinematics: scan over the lanes
@@ -73,12 +77,14 @@ DI void fk_scan(const DevModel& md, int r, real q, real* R, real* p) {
 	const int rr = act ? r : 0;
 	real s, c;
 	sincos_joint(q, &s, &c);
+	const bool pris = md.jtype[rr] != 0;  // prismatic: slides along the joint frame's z
+	if (pris) s = 0, c = 1;
 	UNROLL for (int k = 0; k < 3; k++) {
 		const real e0 = md.E[rr][3 * k], e1 = md.E[rr][3 * k + 1], e2 = md.E[rr][3 * k + 2];
 		R[3 * k + 0] = act ? fma(c, e0, s * e1) : kd(k, 0);
 		R[3 * k + 1] = act ? fma(c, e1, -s * e0) : kd(k, 1);
 		R[3 * k + 2] = act ? e2 : kd(k, 2);
-		p[k] = sel0(act, md.xyz[rr][k]);
+		p[k] = sel0(act, fma(pris ? q : 0.0, e2, md.xyz[rr][k]));
 	}
 	fk_scan_step<G, 1>(R, p);
 	fk_scan_step<G, 2>(R, p);
@@ -129,8 +135,16 @@ DI void crba_g(const DevModel& md, int r, const real* R, const real* p, real* Mr
 	const real* h = comp + 1;
 	const real* IO = comp + 4;
 	real S[6], W[6];  // joint twist (z, p x z) and the composite body's wrench under unit acceleration of this joint
-	S[0] = act ? R[2] : 0.0, S[1] = act ? R[5] : 0.0, S[2] = act ? R[8] : 0.0;
-	cross3(p, S, S + 3);
+	{
+		const real ax[3] = {act ? R[2] : 0.0, act ? R[5] : 0.0, act ? R[8] : 0.0};
+		const bool pris = md.jtype[rr] != 0;
+		real pxz[3];
+		cross3(p, ax, pxz);
+		UNROLL for (int a = 0; a < 3; a++) {
+			S[a] = pris ? 0.0 : ax[a];
+			S[3 + a] = pris ? ax[a] : pxz[a];
+		}
+	}
 	{
 		real hv[3], hz[3];
 		cross3(h, S + 3, hv);
@@ -146,9 +160,21 @@ DI void crba_g(const DevModel& md, int r, const real* R, const real* p, real* Mr
 	mm_rt<G, 6, N>(S, W, m2);
 	UNROLL for (int j = 0; j < N; j++) Mrow[j] = (j <= r) ? m1[j] : m2[j];
 	if (want_g) {  // Sai2Model::jointGravityVector (RobotController.cpp:71)
-		real d[3] = {h[0] - mt * p[0], h[1] - mt * p[1], h[2] - mt * p[2]}, xg[3];
-		cross3(S, d, xg);
-		*g = -(xg[0] * md.gravity[0] + xg[1] * md.gravity[1] + xg[2] * md.gravity[2]);
+		// generalised gravity force on the composite body: -(omega . (h x g) + v . (m g)) with the twist (omega, v)
+		real hg[3];
+		cross3(h, md.gravity, hg);
+		real acc = 0;
+		UNROLL for (int a = 0; a < 3; a++) acc = fma(S[a], hg[a], fma(S[3 + a], mt * md.gravity[a], acc));
+		*g = -acc;
+	}
+}
+
+// out[i] = the value `x` of lane i, i < n, in every lane
+template <int G, int i, int n>
+DI void bcast_all(real x, real* out) {
+	if constexpr (i < n) {
+		out[i] = bcast<G, i>(x);
+		bcast_all<G, i + 1, n>(x, out);
 	}
 }
 
@@ -322,11 +348,11 @@ SAI2B_TASK_FN void mft_task_g(const DevParams& P, const DevTask& t, const Rob& r
 		const real d[3] = {x[0] - rb.Fp[0], x[1] - rb.Fp[1], x[2] - rb.Fp[2]};
 		real v[3];
 		cross3(z, d, v);
-		const bool on = rN && r <= t.link;
+		const bool on = rN && r <= t.link, pris = P.model.jtype[rN ? r : 0] != 0;
 		real jw[6];
 		UNROLL for (int k = 0; k < 3; k++) {
-			jw[k] = on ? v[k] : 0.0;
-			jw[3 + k] = on ? z[k] : 0.0;
+			jw[k] = on ? (pris ? z[k] : v[k]) : 0.0;
+			jw[3 + k] = (on && !pris) ? z[k] : 0.0;
 		}
 		if (t.full_projection) {
 			UNROLL for (int i = 0; i < 6; i++) jT[i] = jw[i];
@@ -520,14 +546,12 @@ SAI2B_TASK_FN void mft_task_g(const DevParams& P, const DevTask& t, const Rob& r
 				v = hit ? x6[j] : v;
 			}
 			real u[6];
-			u[0] = bcast<G, 0>(wsel), u[1] = bcast<G, 1>(wsel), u[2] = bcast<G, 2>(wsel);
-			u[3] = bcast<G, 3>(wsel), u[4] = bcast<G, 4>(wsel), u[5] = bcast<G, 5>(wsel);
+			bcast_all<G, 0, 6>(wsel, u);
 			real inv = s > 0 ? 1.0 / s : 0.0;
 			{  // sign convention shared with the oracle: largest-magnitude component of v positive
 				real big = 0, bigabs = -1;
 				real vi[N];
-				vi[0] = bcast<G, 0>(v), vi[1] = bcast<G, 1>(v), vi[2] = bcast<G, 2>(v), vi[3] = bcast<G, 3>(v);
-				vi[4] = bcast<G, 4>(v), vi[5] = bcast<G, 5>(v), vi[6] = bcast<G, 6>(v);
+				bcast_all<G, 0, N>(v, vi);
 				UNROLL for (int i = 0; i < N; i++) {
 					const bool take = fabs(vi[i]) > bigabs;
 					bigabs = take ? fabs(vi[i]) : bigabs;

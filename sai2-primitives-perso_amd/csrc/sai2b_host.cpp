@@ -20,11 +20,15 @@ using sai2b::rot_from_rpy;
 using sai2b::sym3_from6;
 using sai2b::DevParams;
 using sai2b::DevTask;
-constexpr int N = SAI2B_DOF;
+constexpr int N = SAI2B_N;  // joints of the robots this build serves (sai2b_params.h)
 
 static thread_local std::string g_error;
 
+// defined once for the whole library by sai2b_dispatch.cpp: the error text of calls that have no context
+extern "C" void sai2b_shared_error_set(const char* msg);
+
 struct sai2b_ctx {
+	int dof_tag = N;  // FIRST member: sai2b_dispatch.cpp reads it to route a call to the build for this robot size
 	int B = 0, T = 0, device = 0;
 	bool introspection = false;
 	bool models_fresh = false;	// update_task_models() ran for the current state
@@ -77,6 +81,7 @@ struct sai2b_ctx {
 
 static int set_error(sai2b_ctx* ctx, int code, const std::string& msg) {
 	g_error = msg;
+	sai2b_shared_error_set(msg.c_str());
 	if (ctx) ctx->error = msg;
 	return code;
 }
@@ -199,8 +204,6 @@ static int full_pivot_rank(int rows, int cols, const double* A_in) {
 // ------------------------------------------------------------------------------------------------
 // configuration helpers (host only)
 // ------------------------------------------------------------------------------------------------
-// used by the host-only translation units of the library (sai2b_urdf.cpp)
-extern "C" int sai2b_set_global_error(int code, const char* msg) { return set_error(nullptr, code, msg ? msg : ""); }
 
 extern "C" int sai2b_model_merge_fixed_body(sai2b_robot_model* md, int link, const double xyz[3], const double rpy[3],
 											double mass, const double com[3], const double inertia[6]) {
@@ -258,6 +261,7 @@ extern "C" int sai2b_default_joint_task(sai2b_task_config* c, const char* name, 
 	}
 	c->use_internal_otg = 1;  // JointTask.h:38-39: on, acceleration-limited
 	c->internal_otg_jerk_limited = 0;
+	c->robot_dof = N;
 	return SAI2B_OK;
 }
 
@@ -312,6 +316,7 @@ extern "C" int sai2b_default_motion_force_task(sai2b_task_config* c, const char*
 	c->internal_otg_jerk_limited = 0;
 	c->otg_max_linear_velocity = 0.3, c->otg_max_linear_acceleration = 2.0;
 	c->otg_max_angular_velocity = M_PI / 3, c->otg_max_angular_acceleration = 2.0 * M_PI;
+	c->robot_dof = N;
 	return SAI2B_OK;
 }
 
@@ -326,6 +331,8 @@ extern "C" int sai2b_validate_tasks(const sai2b_task_config* tasks, int n_tasks,
 		const sai2b_task_config& t = tasks[i];
 		if (t.type != SAI2B_JOINT_TASK && t.type != SAI2B_MOTION_FORCE_TASK)
 			err = "task type must be JOINT_TASK or MOTION_FORCE_TASK";
+		else if ((t.robot_dof ? t.robot_dof : SAI2B_DOF) != N)
+			err = "task was configured for a robot with another number of joints (sai2b_task_config.robot_dof)";
 		else if (t.loop_timestep != tasks[0].loop_timestep)
 			err = "All tasks must have the same loop timestep in RobotController";
 		for (int j = 0; err.empty() && j < i; j++)
@@ -532,7 +539,7 @@ static void fill_dev_task(const sai2b_task_config& c, DevTask& d) {
 	// internal OTG: one generator DoF per task dof (JT) or 3 linear + 3 angular (MFT)
 	d.otg_on = c.use_internal_otg ? 1 : 0;
 	d.otg_n = c.type == SAI2B_JOINT_TASK ? c.task_dof : 6;
-	for (int i = 0; i < N; i++) {
+	for (int i = 0; i < sai2b::OTG_MD; i++) {
 		if (c.type == SAI2B_JOINT_TASK) {
 			d.otg_vmax[i] = i < c.task_dof ? c.otg_max_velocity[i] : 0.0;
 			d.otg_amax[i] = i < c.task_dof ? c.otg_max_acceleration[i] : 0.0;
@@ -603,13 +610,14 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	std::memset(&hp, 0, sizeof(hp));
 	hp.B = batch, hp.n_tasks = n_tasks;
 	sai2b::host_fill_dev_model(*model, hp.model);
-	{
+	if constexpr (N == 7) {
 		using PB = sai2b::PandaBaked;
 		const DevModel& m = hp.model;
 		ctx->baked_model = std::memcmp(m.E, PB::E, sizeof(m.E)) == 0 && std::memcmp(m.xyz, PB::xyz, sizeof(m.xyz)) == 0 &&
 						   std::memcmp(m.mass, PB::mass, sizeof(m.mass)) == 0 && std::memcmp(m.com, PB::com, sizeof(m.com)) == 0 &&
 						   std::memcmp(m.inertia, PB::inertia, sizeof(m.inertia)) == 0 &&
-						   std::memcmp(m.gravity, PB::gravity, sizeof(m.gravity)) == 0;
+						   std::memcmp(m.gravity, PB::gravity, sizeof(m.gravity)) == 0 &&
+						   std::memcmp(m.jtype, PB::jtype, sizeof(m.jtype)) == 0;
 		if (const char* e = std::getenv("SAI2B_NO_BAKED_MODEL"))
 			if (e[0] == '1') ctx->baked_model = false;
 	}
@@ -662,9 +670,14 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 extern "C" sai2b_ctx* sai2b_create(const sai2b_robot_model* model, const sai2b_task_config* tasks, int n_tasks, int batch,
 								   int device) {
 	if (!model || model->dof != N) {
-		set_error(nullptr, SAI2B_INVALID_ARGUMENT, "sai2b_create: model must have dof == 7 in this build");
+		set_error(nullptr, SAI2B_INVALID_ARGUMENT, "sai2b_create: robot model has a number of joints this library was not built for");
 		return nullptr;
 	}
+	for (int i = 0; i < N; i++)
+		if (model->joint_type[i] != SAI2B_REVOLUTE && model->joint_type[i] != SAI2B_PRISMATIC) {
+			set_error(nullptr, SAI2B_INVALID_ARGUMENT, "sai2b_create: joint_type must be SAI2B_REVOLUTE or SAI2B_PRISMATIC");
+			return nullptr;
+		}
 	if (batch < 1) {
 		set_error(nullptr, SAI2B_INVALID_ARGUMENT, "sai2b_create: batch must be >= 1");
 		return nullptr;
@@ -902,6 +915,10 @@ extern "C" int sai2b_reinitialize(sai2b_ctx* ctx) {
 // eligibility of the SVD-free path (sai2b_fast.hpp): [full MFT] or [full MFT, full JT] (any batch size: a robot
 // the kernel declines goes to the generic kernel on its own, lanes past the batch just exit)
 static int fast_kind(const sai2b_ctx* ctx) {
+	// the SVD-free kernels are written for 7 revolute joints (a 6-DOF task leaves a one-dimensional nullspace)
+	if (N != 7) return 0;
+	for (int i = 0; i < N; i++)
+		if (ctx->model.joint_type[i] != SAI2B_REVOLUTE) return 0;
 	// the passivity observer mutates per-robot state inside the law: generic kernel only
 	if (ctx->cfg[0].passivity_enabled && ctx->cfg[0].closed_loop_force) return 0;
 	if (ctx->no_fast_path || ctx->T > 2 || ctx->cfg[0].type != SAI2B_MOTION_FORCE_TASK ||

@@ -97,6 +97,7 @@ __global__ __launch_bounds__(64) void tick_kernel(const DevParams* __restrict__ 
 	}
 }
 
+#if SAI2B_N == 7  // the SVD-free kernels are for 7-joint robots (6-DOF task + a one-dimensional nullspace)
 // FAST = 1: hierarchy [full MFT]; FAST = 2: [full MFT, full JT] — the SVD-free path of
 // sai2b_fast.hpp. A robot takes it only when it is certified non-singular (and is not leaving a
 // singular region); otherwise its lane touches no state and appends the robot to the work list of
@@ -139,7 +140,10 @@ __global__ __launch_bounds__(64) void tick_fast_kernel(const DevParams* __restri
 			fk(P.model, rc.q, F);
 		real x[3], R[9];
 		frame_pose(t0, F, x, R);
-		jacobian(t0, F, x, J);
+		if constexpr (BAKED)
+			jacobian(PandaBaked{}, t0, F, x, J);
+		else
+			jacobian(P.model, t0, F, x, J);
 		SAI2B_PHASE();
 		mft_law(t0, rc, J, x, R, in0, Fu, Ff);	// MotionForceTask.cpp:278-503 (integrators not yet stored)
 		SAI2B_PHASE();
@@ -180,6 +184,8 @@ __global__ __launch_bounds__(64) void tick_fast_kernel(const DevParams* __restri
 	fast_tick<FAST == 2>(P, J, M, Fu, Ff, B, b, with_comp != 0, jt, tau);
 	UNROLL for (int i = 0; i < N; i++) st(P.tau, i, B, b, tau[i] + g[i]);
 }
+
+#endif	// SAI2B_N == 7
 
 // One task driven on its own, the reference's plugin interface (TemplateTask.h:42-88):
 //   updateTaskModel(N_prec)            -> do_torque = 0: the task's nullspace N and N * N_prec; the once-per-
@@ -286,6 +292,7 @@ __global__ __launch_bounds__(64) void reinit_kernel(const DevParams* __restrict_
 
 static void launch_fast(int fast, int baked, dim3 grid, dim3 block, hipStream_t stream, const sai2b::DevParams* d_params,
 						int with_comp, int* fb_counts, int* fb_list, int parity) {
+#if SAI2B_N == 7
 	if (fast == 2 && baked)
 		hipLaunchKernelGGL((sai2b::tick_fast_kernel<2, true>), grid, block, 0, stream, d_params, with_comp, fb_counts, fb_list, parity);
 	else if (fast == 2)
@@ -294,6 +301,7 @@ static void launch_fast(int fast, int baked, dim3 grid, dim3 block, hipStream_t 
 		hipLaunchKernelGGL((sai2b::tick_fast_kernel<1, true>), grid, block, 0, stream, d_params, with_comp, fb_counts, fb_list, parity);
 	else
 		hipLaunchKernelGGL((sai2b::tick_fast_kernel<1, false>), grid, block, 0, stream, d_params, with_comp, fb_counts, fb_list, parity);
+#endif
 }
 
 extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int commit_sh,

@@ -26,8 +26,6 @@ inline void sym3_from6(const double* v, double* I) {
 // Merge a fixed child body into link `link` (what RBDL does for URDF fixed joints)
 inline void host_merge_fixed_body(sai2b_robot_model* md, int link, const double xyz[3], const double rpy[3], double mass,
 								  const double com[3], const double inertia[6]) {
-	constexpr int N = SAI2B_DOF;
-	(void)N;
 	double Rf[9], Ic[9], Iw[9] = {0};
 	rot_from_rpy(rpy, Rf);
 	sym3_from6(inertia, Ic);
@@ -61,7 +59,7 @@ inline void host_merge_fixed_body(sai2b_robot_model* md, int link, const double 
 
 // Panda arm constants (reference examples/15-haptic_control_impedance_type/panda_arm.urdf:4-184)
 inline void host_panda_model(sai2b_robot_model* md) {
-	constexpr int N = SAI2B_DOF;
+	constexpr int N = 7;
 	std::memset(md, 0, sizeof(*md));
 	md->dof = N;
 	// examples/15-haptic_control_impedance_type/panda_arm.urdf:118-178 (joint origins / limits)
@@ -99,8 +97,8 @@ inline void host_panda_model(sai2b_robot_model* md) {
 
 // constant part of the device parameter block from the C-ABI model
 inline void host_fill_dev_model(const sai2b_robot_model& model, DevModel& dm) {
-	constexpr int N = SAI2B_DOF;
 	for (int i = 0; i < N; i++) {
+		dm.jtype[i] = model.joint_type[i];
 		rot_from_rpy(model.joint_rpy[i], dm.E[i]);
 		for (int k = 0; k < 3; k++) dm.xyz[i][k] = model.joint_xyz[i][k], dm.com[i][k] = model.link_com[i][k];
 		for (int k = 0; k < 6; k++) dm.inertia[i][k] = model.link_inertia[i][k];

@@ -19,6 +19,9 @@
 
 #include "sai2b_device.hpp"
 #include "sai2b_launch.h"
+#if SAI2B_N > 7
+#define SAI2B_OTG_MAXD SAI2B_N
+#endif
 #include "sai2b_otg_core.hpp"
 #include "sai2b_otg_group.hpp"
 
@@ -27,6 +30,7 @@ namespace {
 
 using otg::Gen;
 constexpr int MD = otg::MAXD;
+static_assert(MD == OTG_MD, "generator DoFs and the state row layout (sai2b_params.h) must agree");
 
 DI void load7(const real* S, int row0, int n, int B, int b, double (&v)[MD]) {
 	UNROLL for (int d = 0; d < MD; d++) v[d] = d < n ? ld(S, row0 + d, B, b) : 0.0;

@@ -33,7 +33,10 @@
 namespace sai2b {
 namespace otg {
 
-constexpr int MAXD = 7;
+#ifndef SAI2B_OTG_MAXD
+#define SAI2B_OTG_MAXD 7  // DoFs of the largest generator; the 8-joint build of the library sets 8 (sai2b_params.h: OTG_MD)
+#endif
+constexpr int MAXD = SAI2B_OTG_MAXD;
 constexpr int WORKING = 0, FINISHED = 1, ERR_INVALID_INPUT = -100, ERR_TRAJECTORY_DURATION = -101,
 			  ERR_EXECUTION_TIME = -110, ERR_SYNCHRONIZATION = -111;
 constexpr double EPS = 2.220446049250313e-16;

@@ -22,7 +22,7 @@ namespace otgg {
 using otg::Block;
 using otg::Dof;
 using otg::Prof;
-constexpr int G = 8;  // lanes per group; DoF j < n <= 7 active
+constexpr int G = 8;  // lanes per group; DoF j < n <= 8 active
 
 DI int lane_j() { return threadIdx.x & (G - 1); }
 DI int group_base() { return threadIdx.x & ~(G - 1); }

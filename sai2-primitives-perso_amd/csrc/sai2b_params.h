@@ -6,7 +6,14 @@
 
 namespace sai2b {
 
-constexpr int N = SAI2B_DOF;
+// joints of the robots this build of the library serves: every translation unit is compiled once per supported
+// value (Makefile: 4, 6, 7, 8) with its symbols suffixed (sai2b_dof_rename.h); sai2b_dispatch.cpp routes the
+// public entry points by the model's / the context's dof
+#ifndef SAI2B_N
+#define SAI2B_N 7
+#endif
+constexpr int N = SAI2B_N;
+static_assert(N >= 1 && N <= SAI2B_MAX_DOF, "SAI2B_N");
 
 // sai2-model subset: constant part of the kinematic/dynamic model
 struct DevModel {
@@ -17,7 +24,10 @@ struct DevModel {
 	double inertia[N][6]; // ixx iyy izz ixy ixz iyz at the COM, link axes
 	double q_lower[N], q_upper[N], effort[N];
 	double gravity[3];
+	int jtype[N];  // enum sai2b_joint_type: 0 = revolute about, 1 = prismatic along the joint frame's z
 };
+
+constexpr int OTG_MD = N > 7 ? N : 7;  // DoFs of the largest generator (a full JointTask; the Cartesian one has 6)
 
 // batch-uniform task parameters (sai2b_task_config flattened for the device)
 struct DevTask {
@@ -64,7 +74,7 @@ struct DevTask {
 	// the generator is touched): a model-only pass ahead of otg_kernel writes OTG_ACTIVE per robot and
 	// the generator of an inactive robot is left alone for that tick
 	int otg_gated;
-	double otg_vmax[N], otg_amax[N];
+	double otg_vmax[OTG_MD], otg_amax[OTG_MD];
 	double otg_epoch;  // bumped when the limits change: every moving robot re-plans on its next tick
 	// device buffers of this task
 	double* goals;	// MFT [30][B]: pos3 rot9 v3 w3 a3 alpha3 f3 m3 ; JT [3*k0][B]: q dq ddq
@@ -89,21 +99,21 @@ struct DevTask {
 constexpr int MFT_GOAL_ROWS = 30;
 constexpr int MFT_MOTION_GOAL_ROWS = 24;  // pos rot v w a alpha: the rows the OTG replaces
 // rows of otg_state (one OTG_joints / OTG_6dof_cartesian object per robot; sai2b_otg_core.hpp: Gen)
-constexpr int OTG_IN = 0;	  // wrapper _input: cp cv ca tp tv, 7 rows each
-constexpr int OTG_CI = 35;	  // Ruckig current_input: cp cv ca tp tv
-constexpr int OTG_OUT = 70;	  // _output: new position, velocity, acceleration
-constexpr int OTG_TIME = 91, OTG_DURATION = 92, OTG_GOAL_REACHED = 93, OTG_RESULT = 94, OTG_TARGET_SET = 95,
-			  OTG_CI_INIT = 96, OTG_CI_EPOCH = 97, OTG_CONSTRUCTED = 98;
+constexpr int OTG_IN = 0;	  // wrapper _input: cp cv ca tp tv, OTG_MD rows each
+constexpr int OTG_CI = 5 * OTG_MD;	  // Ruckig current_input: cp cv ca tp tv
+constexpr int OTG_OUT = 10 * OTG_MD;	  // _output: new position, velocity, acceleration
+constexpr int OTG_TIME = 13 * OTG_MD, OTG_DURATION = OTG_TIME + 1, OTG_GOAL_REACHED = OTG_TIME + 2, OTG_RESULT = OTG_TIME + 3,
+			  OTG_TARGET_SET = OTG_TIME + 4, OTG_CI_INIT = OTG_TIME + 5, OTG_CI_EPOCH = OTG_TIME + 6, OTG_CONSTRUCTED = OTG_TIME + 7;
 // OTG_IN_SYNC != 0: the wrapper's input state and Ruckig's stored one both equal the output (the normal
 // case after a step along the trajectory: pass_to_input twice, OTG_joints.cpp:137, ruckig.hpp:209) and
 // the stored targets are equal; their rows (IN c*, CI c*, CI t*) are then not kept up to date
-constexpr int OTG_IN_SYNC = 190 + 21;  // = OTG_CART + 21
-constexpr int OTG_TRAJ = 99;  // per DoF: brake t a p v, p0 v0, t0 t1 t2 t6, a0 a2 a6
+constexpr int OTG_TRAJ = OTG_TIME + 8;  // per DoF: brake t a p v, p0 v0, t0 t1 t2 t6, a0 a2 a6
 constexpr int OTG_TRAJ_STRIDE = 13;
-constexpr int OTG_CART = OTG_TRAJ + 7 * OTG_TRAJ_STRIDE;  // reference frame 9, goal orientation 9, goal angular velocity 3
+constexpr int OTG_CART = OTG_TRAJ + OTG_MD * OTG_TRAJ_STRIDE;  // reference frame 9, goal orientation 9, goal angular velocity 3
+constexpr int OTG_IN_SYNC = OTG_CART + 21;
 constexpr int OTG_ACTIVE = OTG_CART + 22;  // gated JointTask only: 1 = the task has a non-empty range this tick
 constexpr int OTG_ROWS = OTG_CART + 23;
-static_assert(OTG_IN_SYNC == OTG_CART + 21, "row layout");
+static_assert(N > 7 || (OTG_TRAJ == 99 && OTG_CART == 190 && OTG_IN_SYNC == 211), "row layout of the 7-DoF builds");
 constexpr int MFT_STATE_ROWS = 33;
 constexpr int MFT_ISTATE_ROWS = 12;
 constexpr int POPC_RING = 1024;	 // capacity of the PO window ring (the reference queue is unbounded)

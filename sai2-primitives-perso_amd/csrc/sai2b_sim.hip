@@ -37,9 +37,14 @@ DI void bias_forces(const MD& md, const Frames& Fr, const real* dq, bool with_gr
 		UNROLL for (int k = 0; k < 3; k++) a[k] += t1[k] + t3[k];
 		real zq[3] = {z[0] * dq[i], z[1] * dq[i], z[2] * dq[i]};
 		cross3(w, zq, t1);
+		const bool pris = md.jtype[i] != 0;
 		UNROLL for (int k = 0; k < 3; k++) {
-			w[k] += zq[k];
-			al[k] += t1[k];
+			if (pris) {	 // sliding frame: Coriolis acceleration of its origin, no change of the angular motion
+				a[k] += 2 * t1[k];
+			} else {
+				w[k] += zq[k];
+				al[k] += t1[k];
+			}
 			o[k] = Fr.p[i][k];
 		}
 		UNROLL for (int k = 0; k < 3; k++)
@@ -78,7 +83,8 @@ DI void bias_forces(const MD& md, const Frames& Fr, const real* dq, bool with_gr
 			n[k] += Nn[i][k] + t1[k];
 			f[k] += F[i][k];
 		}
-		b[i] = Fr.R[i][2] * n[0] + Fr.R[i][5] * n[1] + Fr.R[i][8] * n[2];
+		const real* pr = (md.jtype[i] != 0) ? f : n;  // prismatic: the force along the axis
+		b[i] = Fr.R[i][2] * pr[0] + Fr.R[i][5] * pr[1] + Fr.R[i][8] * pr[2];
 	}
 }
 
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(64) void mft_status_kernel(const DevParams* __restr
 	frame_pose(t, F, x, R);
 	{  // getCurrentLinearVelocity / getCurrentAngularVelocity (MotionForceTask.h:127-146, MotionForceTask.cpp:293-298)
 		real J[6 * N], v[6];
-		jacobian(t, F, x, J);
+		jacobian(P.model, t, F, x, J);
 		mv<6, N>(J, dq, v);
 		UNROLL for (int k = 0; k < 6; k++) st(out, 26 + k, B, b, v[k]);
 	}

@@ -8,11 +8,12 @@
 // a position in that link (MotionForceTask.h:96-101: link_name "end-effector", a body on a fixed joint
 // of link7) into (moving link index, compliant frame).
 //
-// Scope of this build: one serial chain of exactly SAI2B_DOF revolute joints about their local z axis
-// ("0 0 1": the convention of every robot file in the reference's examples), any number of fixed
-// joints (bodies behind them are merged into their parent, as RBDL does), <inertial> origins with
-// rotation. Anything else is refused with a message. No XML library: URDF needs elements, attributes
-// and comments only.
+// Scope: one serial chain of 4, 6, 7 or 8 revolute / continuous / prismatic joints (the sizes the library is built
+// for) with any <axis>, any number of fixed joints anywhere (bodies behind them are merged into the moving link
+// they hang on, as RBDL does), <inertial> origins with rotation. The kernels move every joint about / along the z
+// axis of its joint frame: a joint with another axis gets its frame rotated by A (A z = axis) and everything
+// that hangs on the child link is re-expressed in the rotated link frame (sai2b.h: sai2b_robot_model).
+// Anything else is refused with a message. No XML library: URDF needs elements, attributes and comments only.
 #include <cctype>
 #include <cmath>
 #include <cstdio>
@@ -140,16 +141,21 @@ struct Parser {
 	}
 };
 
+// n whitespace-separated numbers. Each token is read like std::stod does (a numeric prefix, the rest ignored):
+// examples/06-partial_joint_task/panda_arm_sliding_base.urdf:172 has xyz="0 0 0.-75", which the reference's
+// reader takes as 0 0 0.
 bool numbers(const std::string& text, int n, double* out) {
-	const char* p = text.c_str();
-	for (int k = 0; k < n; k++) {
+	std::istringstream ss(text);
+	std::string tok;
+	int k = 0;
+	while (ss >> tok) {
+		if (k >= n) return false;
 		char* end = nullptr;
-		out[k] = std::strtod(p, &end);
-		if (end == p) return false;
-		p = end;
+		out[k] = std::strtod(tok.c_str(), &end);
+		if (end == tok.c_str()) return false;
+		k++;
 	}
-	while (*p && std::isspace((unsigned char)*p)) p++;
-	return *p == 0;
+	return k == n;
 }
 
 struct Inertial {
@@ -197,10 +203,37 @@ void rotate_inertia(const double* I6, const double* rpy, double* out6) {
 
 int fail(const std::string& m) { return sai2b_set_global_error(SAI2B_INVALID_ARGUMENT, m.c_str()); }
 
+// rotation A with A z = a (a unit): identity for a = z, a half turn about x for a = -z, else the rotation about z x a
+void axis_frame(const double* a, double* A) {
+	const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+	std::memcpy(A, I, sizeof(I));
+	if (a[0] == 0 && a[1] == 0 && a[2] == 1) return;
+	if (a[0] == 0 && a[1] == 0 && a[2] == -1) {
+		A[4] = A[8] = -1;
+		return;
+	}
+	const double v[3] = {-a[1], a[0], 0.0}, c = a[2], s2 = v[0] * v[0] + v[1] * v[1];  // v = z x a
+	const double K[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+	double K2[9];
+	mat_mul(K, K, K2);
+	for (int i = 0; i < 9; i++) A[i] = I[i] + K[i] + K2[i] * (1 - c) / s2;
+}
+// rpy with rot_from_rpy(rpy) == R (R = Rz(y) Ry(p) Rx(r))
+void rpy_from_rot(const double* R, double* rpy) {
+	rpy[1] = std::atan2(-R[6], std::sqrt(R[0] * R[0] + R[3] * R[3]));
+	rpy[2] = std::atan2(R[3], R[0]);
+	rpy[0] = std::atan2(R[7], R[8]);
+}
+bool is_identity(const double* R) {
+	for (int i = 0; i < 9; i++)
+		if (R[i] != (i % 4 == 0 ? 1.0 : 0.0)) return false;
+	return true;
+}
+
 }  // namespace
 
 extern "C" int sai2b_model_from_urdf(const char* urdf, int is_file, sai2b_robot_model* model, sai2b_urdf_links* links) {
-	constexpr int N = SAI2B_DOF;
+	constexpr int N = SAI2B_MAX_DOF;
 	if (!urdf || !model) return fail("sai2b_model_from_urdf: null argument");
 	std::string text;
 	if (is_file) {
@@ -296,17 +329,17 @@ extern "C" int sai2b_model_from_urdf(const char* urdf, int is_file, sai2b_robot_
 	// walk the tree from the root: every link gets (moving link it is rigidly attached to, fixed
 	// transform there); a revolute joint starts a new moving link
 	std::memset(model, 0, sizeof(*model));
-	model->dof = N;
 	model->gravity[2] = -9.81;	// Sai2Model's default world gravity
 	struct Placed {
 		int moving;	 // -1: fixed to the world
 		double R[9], p[3];
 		int depth;	 // fixed joints between the moving link and this one
 		double rpy1[3];	 // the rpy of that joint when depth == 1 (exact re-use of the model's own merge)
+		bool exact = false;	 // depth == 1 on a moving link whose own frame is not re-oriented: R == rot(rpy1), p == xyz bit for bit
 	};
 	std::vector<Placed> placed(lk.size());
 	std::vector<int> order = {root};
-	placed[root] = Placed{-1, {1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, 0, 0}, 0, {0, 0, 0}};
+	placed[root] = Placed{-1, {1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, 0, 0}, 0, {0, 0, 0}, false};
 	int n_moving = 0;
 	for (size_t head = 0; head < order.size(); head++) {
 		const int cur = order[head];
@@ -323,35 +356,71 @@ extern "C" int sai2b_model_from_urdf(const char* urdf, int is_file, sai2b_robot_
 					pl.p[a] = placed[cur].p[a] + placed[cur].R[3 * a] * j.xyz[0] + placed[cur].R[3 * a + 1] * j.xyz[1] + placed[cur].R[3 * a + 2] * j.xyz[2];
 				std::memcpy(pl.R, Rn, sizeof(Rn));
 				pl.depth = placed[cur].depth + 1;
+				pl.exact = placed[cur].depth == 0 && is_identity(placed[cur].R) && placed[cur].p[0] == 0 && placed[cur].p[1] == 0 && placed[cur].p[2] == 0;
 				std::memcpy(pl.rpy1, j.rpy, sizeof(pl.rpy1));
 				placed[c] = pl;
-			} else if (j.type == "revolute" || j.type == "continuous") {
-				if (!(j.axis[0] == 0 && j.axis[1] == 0 && j.axis[2] == 1))
-					return fail("URDF: joint " + j.name + " does not turn about its local z axis (only \"0 0 1\" is supported in this build)");
-				if (placed[cur].depth != 0)
-					return fail("URDF: joint " + j.name + " hangs on a link behind a fixed joint (not supported in this build)");
+			} else if (j.type == "revolute" || j.type == "continuous" || j.type == "prismatic") {
 				if (placed[cur].moving != n_moving - 1)
 					return fail("URDF: the moving joints do not form one serial chain (branch at joint " + j.name + ")");
-				if (n_moving >= N) return fail("URDF: more than " + std::to_string(N) + " moving joints (this build is compiled for 7)");
+				if (n_moving >= N) return fail("URDF: more than " + std::to_string(N) + " moving joints (the largest robot this library is built for)");
+				double an = std::sqrt(j.axis[0] * j.axis[0] + j.axis[1] * j.axis[1] + j.axis[2] * j.axis[2]);
+				if (!(an > 1e-9)) return fail("URDF: joint " + j.name + " has a zero axis");
+				const double axis[3] = {j.axis[0] / an, j.axis[1] / an, j.axis[2] / an};
+				double A[9];
+				axis_frame(axis, A);
 				const int i = n_moving++;
-				for (int a = 0; a < 3; a++) model->joint_xyz[i][a] = j.xyz[a], model->joint_rpy[i][a] = j.rpy[a];
+				const Placed& par = placed[cur];
+				const bool plain = par.depth == 0 && is_identity(par.R) && par.p[0] == 0 && par.p[1] == 0 && par.p[2] == 0 && is_identity(A);
+				if (plain) {  // the file's own numbers, bit for bit
+					for (int a = 0; a < 3; a++) model->joint_xyz[i][a] = j.xyz[a], model->joint_rpy[i][a] = j.rpy[a];
+				} else {  // joint frame in the (possibly re-oriented) parent link frame, turned so that the axis is its z
+					double Rj[9], T[9], E[9];
+					sai2b::rot_from_rpy(j.rpy, Rj);
+					mat_mul(par.R, Rj, T);
+					mat_mul(T, A, E);
+					rpy_from_rot(E, model->joint_rpy[i]);
+					for (int a = 0; a < 3; a++)
+						model->joint_xyz[i][a] = par.p[a] + par.R[3 * a] * j.xyz[0] + par.R[3 * a + 1] * j.xyz[1] + par.R[3 * a + 2] * j.xyz[2];
+				}
+				model->joint_type[i] = j.type == "prismatic" ? SAI2B_PRISMATIC : SAI2B_REVOLUTE;
 				model->q_lower[i] = j.type == "continuous" ? -1e30 : j.lower;
 				model->q_upper[i] = j.type == "continuous" ? 1e30 : j.upper;
 				model->effort[i] = j.effort;
+				// the child link's own frame in the model's link frame: A^T (identity for a z-axis joint)
+				Placed me{i, {A[0], A[3], A[6], A[1], A[4], A[7], A[2], A[5], A[8]}, {0, 0, 0}, 0, {0, 0, 0}, false};
 				if (lk[c].in.present) {
 					model->link_mass[i] = lk[c].in.mass;
-					for (int a = 0; a < 3; a++) model->link_com[i][a] = lk[c].in.com[a];
-					rotate_inertia(lk[c].in.I6, lk[c].in.rpy, model->link_inertia[i]);
+					if (is_identity(A)) {
+						for (int a = 0; a < 3; a++) model->link_com[i][a] = lk[c].in.com[a];
+						rotate_inertia(lk[c].in.I6, lk[c].in.rpy, model->link_inertia[i]);
+					} else {
+						double I6[6], I[9], T[9], W[9];
+						rotate_inertia(lk[c].in.I6, lk[c].in.rpy, I6);
+						sai2b::sym3_from6(I6, I);
+						mat_mul(me.R, I, T);
+						for (int a = 0; a < 3; a++)
+							for (int b = 0; b < 3; b++) {
+								double v = 0;
+								for (int k2 = 0; k2 < 3; k2++) v += T[3 * a + k2] * me.R[3 * b + k2];
+								W[3 * a + b] = v;
+							}
+						double* o = model->link_inertia[i];
+						o[0] = W[0], o[1] = W[4], o[2] = W[8], o[3] = W[1], o[4] = W[2], o[5] = W[5];
+						for (int a = 0; a < 3; a++)
+							model->link_com[i][a] = me.R[3 * a] * lk[c].in.com[0] + me.R[3 * a + 1] * lk[c].in.com[1] + me.R[3 * a + 2] * lk[c].in.com[2];
+					}
 				}
-				placed[c] = Placed{i, {1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, 0, 0}, 0, {0, 0, 0}};
+				placed[c] = me;
 			} else {
-				return fail("URDF: joint " + j.name + " has type \"" + j.type + "\" (only revolute, continuous and fixed are supported in this build)");
+				return fail("URDF: joint " + j.name + " has type \"" + j.type + "\" (revolute, continuous, prismatic and fixed are supported)");
 			}
 			order.push_back(c);
 		}
 	}
 	if (order.size() != lk.size()) return fail("URDF: some links are not connected to the root");
-	if (n_moving != N) return fail("URDF: " + std::to_string(n_moving) + " moving joints; this build is compiled for exactly " + std::to_string(N));
+	if (n_moving != 4 && n_moving != 6 && n_moving != 7 && n_moving != 8)
+		return fail("URDF: " + std::to_string(n_moving) + " moving joints; this library is built for robots with 4, 6, 7 or 8");
+	model->dof = n_moving;
 	// bodies behind fixed joints are merged into the moving link they hang on (in file order of the
 	// tree walk), as RBDL's urdfreader does; bodies fixed to the world carry no dynamics
 	for (size_t h = 1; h < order.size(); h++) {
@@ -360,7 +429,7 @@ extern "C" int sai2b_model_from_urdf(const char* urdf, int is_file, sai2b_robot_
 		if (pl.depth == 0 || pl.moving < 0 || !lk[l].in.present) continue;
 		double I6[6];
 		rotate_inertia(lk[l].in.I6, lk[l].in.rpy, I6);
-		if (pl.depth == 1) {
+		if (pl.depth == 1 && pl.exact) {
 			sai2b::host_merge_fixed_body(model, pl.moving, pl.p, pl.rpy1, lk[l].in.mass, lk[l].in.com, I6);
 		} else {
 			// deeper chains: express the body in the frame of the first fixed link (identity rpy) by

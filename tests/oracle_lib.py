@@ -12,21 +12,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "libsai2_oracle.so")
 
-_lib = None
+_libs = {}
 
 
 def build_oracle():
-    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "all"], check=True)
 
 
-def lib():
-    global _lib
-    if _lib is not None:
-        return _lib
+def lib(dof=DOF):
+    """the oracle built for robots with `dof` joints (oracle/Makefile: one library per size, like the product)"""
+    if dof in _libs:
+        return _libs[dof]
+    path = ORACLE_LIB if dof == DOF else os.path.join(ORACLE_DIR, f"libsai2_oracle_n{dof}.so")
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("sai2_oracle.c", "otg_oracle.c", "otg_oracle.h", "sai2_oracle.h")]
-    if not os.path.exists(ORACLE_LIB) or os.path.getmtime(ORACLE_LIB) < max(os.path.getmtime(f) for f in srcs):
+    if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in srcs):
         build_oracle()
-    L = C.CDLL(ORACLE_LIB)
+    L = C.CDLL(path)
     P, vp, d, i = C.POINTER, C.c_void_p, C.c_double, C.c_int
     dp = P(d)
     L.oracle_panda_model.argtypes = [P(RobotModel)]
@@ -78,7 +79,7 @@ def lib():
     L.oracle_svd.restype = None
     L.oracle_inverse.argtypes = [i, vp, vp]
     L.oracle_range_basis.argtypes = [i, i, vp, d, vp]
-    _lib = L
+    _libs[dof] = L
     return L
 
 
@@ -100,11 +101,11 @@ def panda_model():
     return m
 
 
-def joint_task(name=None, selection=None, internal_otg=False):
+def joint_task(name=None, selection=None, internal_otg=False, robot_dof=DOF):
     """oracle defaults; internal OTG off unless asked (same convention as pkg.joint_task_config)"""
     c = TaskConfig()
     sel = None if selection is None else np.ascontiguousarray(selection, dtype=np.float64)
-    rc = lib().oracle_default_joint_task(
+    rc = lib(robot_dof).oracle_default_joint_task(
         C.byref(c),
         name.encode() if name else None,
         0 if sel is None else sel.shape[0],
@@ -118,7 +119,7 @@ def joint_task(name=None, selection=None, internal_otg=False):
 
 
 def motion_force_task(name=None, link=pkg.workloads.EE_LINK, frame_pos=pkg.workloads.EE_FRAME_POS, frame_rot=None,
-                      partial=None, internal_otg=False):
+                      partial=None, internal_otg=False, robot_dof=DOF):
     c = TaskConfig()
     dp = C.POINTER(C.c_double)
     fp = np.ascontiguousarray(frame_pos, dtype=np.float64)
@@ -129,7 +130,7 @@ def motion_force_task(name=None, link=pkg.workloads.EE_LINK, frame_pos=pkg.workl
         dt = np.ascontiguousarray(partial[0], dtype=np.float64).reshape(-1, 3)
         dr = np.ascontiguousarray(partial[1], dtype=np.float64).reshape(-1, 3)
         nt, nr = dt.shape[0], dr.shape[0]
-    rc = lib().oracle_default_motion_force_task(
+    rc = lib(robot_dof).oracle_default_motion_force_task(
         C.byref(c),
         name.encode() if name else None,
         link,
@@ -162,7 +163,8 @@ class Oracle:
     """Batch driver over the per-robot CPU oracle; same method names as pkg.Controller."""
 
     def __init__(self, model, tasks, batch, threads=1):
-        self.L = lib()
+        self.dof = int(model.dof)
+        self.L = lib(self.dof)
         self.B = batch
         self.tasks = list(tasks)
         arr = (TaskConfig * len(tasks))(*tasks)
@@ -192,7 +194,7 @@ class Oracle:
         self.L.oracle_enable_gravity_compensation(self.h, int(on))
 
     def set_state(self, q, dq):
-        q, dq = _arr(q, (DOF, self.B)), _arr(dq, (DOF, self.B))
+        q, dq = _arr(q, (self.dof, self.B)), _arr(dq, (self.dof, self.B))
         self.L.oracle_set_state(self.h, _ptr(q), _ptr(dq))
 
     def set_mft_goals(self, task, pos=None, rot=None, v=None, w=None, a=None, alpha=None):
@@ -225,23 +227,23 @@ class Oracle:
         self.L.oracle_update_task_models(self.h)
 
     def compute_control_torques(self, with_compensation=True):
-        tau = np.empty((DOF, self.B))
+        tau = np.empty((self.dof, self.B))
         self.L.oracle_compute_control_torques(self.h, _ptr(tau), int(with_compensation))
         return tau
 
     def tick(self, want_output=True):
-        tau = np.empty((DOF, self.B)) if want_output else None
+        tau = np.empty((self.dof, self.B)) if want_output else None
         self.L.oracle_tick(self.h, _ptr(tau))
         return tau
 
     # task-level plugin interface (TemplateTask.h:42-88), same names as pkg.Controller
     def task_update_model(self, task, N_prec=None):
-        N_prec = _arr(N_prec, (DOF * DOF, self.B))
+        N_prec = _arr(N_prec, (self.dof * self.dof, self.B))
         assert self.L.oracle_task_update_model(self.h, task, _ptr(N_prec)) == 0
 
     def task_compute_torques(self, task, tau_prec=None):
-        tau_prec = _arr(tau_prec, (DOF, self.B))
-        tau = np.empty((DOF, self.B))
+        tau_prec = _arr(tau_prec, (self.dof, self.B))
+        tau = np.empty((self.dof, self.B))
         assert self.L.oracle_task_compute_torques(self.h, task, _ptr(tau_prec), _ptr(tau)) == 0
         return tau
 
@@ -249,17 +251,17 @@ class Oracle:
         assert self.L.oracle_task_reinitialize(self.h, task) == 0
 
     def task_nullspaces(self, task):
-        out = [np.empty((DOF * DOF, self.B)) for _ in range(3)]
+        out = [np.empty((self.dof * self.dof, self.B)) for _ in range(3)]
         assert self.L.oracle_task_get_nullspaces(self.h, task, *[_ptr(x) for x in out]) == 0
         return tuple(out)
 
     def get_task_nullspace(self, task):
-        out = np.empty((49, self.B))
+        out = np.empty((self.dof * self.dof, self.B))
         assert self.L.oracle_get_task_nullspace(self.h, task, _ptr(out)) == 0
         return out
 
     def get_task_torques(self, task):
-        out = np.empty((DOF, self.B))
+        out = np.empty((self.dof, self.B))
         assert self.L.oracle_get_task_torques(self.h, task, _ptr(out)) == 0
         return out
 
@@ -269,21 +271,21 @@ class Oracle:
         return s, a, r
 
     def get_model(self, task=-1):
-        M = np.empty((49, self.B))
+        M = np.empty((self.dof * self.dof, self.B))
         if task < 0:
             assert self.L.oracle_get_model(self.h, -1, _ptr(M), None, None, None) == 0
             return M
-        J, x, R = np.empty((42, self.B)), np.empty((3, self.B)), np.empty((9, self.B))
+        J, x, R = np.empty((6 * self.dof, self.B)), np.empty((3, self.B)), np.empty((9, self.B))
         assert self.L.oracle_get_model(self.h, task, _ptr(M), _ptr(J), _ptr(x), _ptr(R)) == 0
         return M, J, x, R
 
     def get_minv(self):
-        out = np.empty((49, self.B))
+        out = np.empty((self.dof * self.dof, self.B))
         self.L.oracle_get_minv(self.h, _ptr(out))
         return out
 
     def get_gravity(self):
-        out = np.empty((DOF, self.B))
+        out = np.empty((self.dof, self.B))
         self.L.oracle_get_gravity(self.h, _ptr(out))
         return out
 
@@ -325,16 +327,16 @@ class Oracle:
         assert self.L.oracle_reset_integrators(self.h, task, which) == 0
 
     def sim_step(self, tau, dt=0.001, substeps=1, with_gravity=False):
-        tau = _arr(tau, (DOF, self.B))
+        tau = _arr(tau, (self.dof, self.B))
         assert self.L.oracle_sim_step(self.h, _ptr(tau), dt, substeps, int(with_gravity)) == 0
 
     def get_state(self):
-        q, dq = np.empty((DOF, self.B)), np.empty((DOF, self.B))
+        q, dq = np.empty((self.dof, self.B)), np.empty((self.dof, self.B))
         self.L.oracle_get_state(self.h, _ptr(q), _ptr(dq))
         return q, dq
 
     def get_bias(self, with_gravity=False):
-        out = np.empty((DOF, self.B))
+        out = np.empty((self.dof, self.B))
         self.L.oracle_get_bias(self.h, int(with_gravity), _ptr(out))
         return out
 
