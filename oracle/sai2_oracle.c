@@ -1033,7 +1033,10 @@ static void sh_update(const oracle_ctx* c, const sai2b_task_config* t, const rob
 					  const double* N_prec) {
 	/* SingularityHandler.cpp:75-228 */
 	int rank = t->pos_range + t->ori_range;
+	const int SVP = N7 < 6 ? N7 : 6; /* the thin SVD of the 6 x n Jacobian has min(6, n) columns */
+	for (int i = 0; i < 6; i++) s->s[i] = 0;
 	oracle_svd(6, N7, s->Jp, s->U, s->s, s->V);
+	if (rank > SVP) rank = SVP; /* a task asking for more directions than the robot has joints: the missing ones are singular by construction */
 	s->ns = s->sc = 0;
 	int split = -1; /* number of non-singular columns */
 	if (s->s[0] < t->s_abs_tol) { /* :83-98 fully singular */
@@ -1056,15 +1059,15 @@ static void sh_update(const oracle_ctx* c, const sai2b_task_config* t, const rob
 	s->sc = rank - split;
 	if (s->ns > 0) {
 		for (int rr = 0; rr < 6; rr++)
-			for (int cc = 0; cc < s->ns; cc++) s->U_ns[rr * s->ns + cc] = s->U[rr * 6 + cc];
+			for (int cc = 0; cc < s->ns; cc++) s->U_ns[rr * s->ns + cc] = s->U[rr * SVP + cc];
 		mm_tn(s->ns, 6, N7, s->U_ns, s->Jp, s->J_ns);
 		opspace(r, s->ns, s->J_ns, s->L_ns, s->Jbar_ns, s->N_ns);
 	}
 	if (s->sc > 0) {
 		for (int rr = 0; rr < 6; rr++)
-			for (int cc = 0; cc < s->sc; cc++) s->U_s[rr * s->sc + cc] = s->U[rr * 6 + split + cc];
+			for (int cc = 0; cc < s->sc; cc++) s->U_s[rr * s->sc + cc] = s->U[rr * SVP + split + cc];
 		for (int rr = 0; rr < N7; rr++)
-			for (int cc = 0; cc < s->sc; cc++) s->V_s[rr * s->sc + cc] = s->V[rr * 6 + split + cc];
+			for (int cc = 0; cc < s->sc; cc++) s->V_s[rr * s->sc + cc] = s->V[rr * SVP + split + cc];
 		mm_tn(s->sc, 6, N7, s->U_s, s->Jp, s->J_s);
 		double T[NN], A[NN];
 		mm(s->sc, N7, N7, s->J_s, r->Minv, T);

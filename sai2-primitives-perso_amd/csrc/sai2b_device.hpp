@@ -891,12 +891,12 @@ DI void mft_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B
 		real qprior[N], t2dir[N];
 		if (commit_sh && (prev_types == 0 || c2 > c1)) {
 			UNROLL for (int i = 0; i < N; i++) {
-				st(S, 12 + i, B, b, rc.q[i]);
-				st(S, 19 + i, B, b, rc.dq[i]);
+				st(S, MFT_QPRIOR + i, B, b, rc.q[i]);
+				st(S, MFT_DQPRIOR + i, B, b, rc.dq[i]);
 				qprior[i] = rc.q[i];
 			}
 		} else {
-			UNROLL for (int i = 0; i < N; i++) qprior[i] = ld(S, 12 + i, B, b);
+			UNROLL for (int i = 0; i < N; i++) qprior[i] = ld(S, MFT_QPRIOR + i, B, b);
 		}
 		// first singular column (descending order) and the singular joint-space range
 		real us0[6], vs0[N], PV[N * N];
@@ -1023,14 +1023,14 @@ DI void mft_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B
 					mv_t<N, N>(Bm, y7, tau_j);
 				} else {
 					UNROLL for (int i = 0; i < N; i++) {
-						real dir = ld(S, 26 + i, B, b);
+						real dir = ld(S, MFT_T2DIR + i, B, b);
 						if (vs0[i] != 0) {
 							if (fabs(rc.q[i] - P.model.q_upper[i]) < t.t2_angle) {
 								dir = -1;
-								if (do_torque) st(S, 26 + i, B, b, dir);
+								if (do_torque) st(S, MFT_T2DIR + i, B, b, dir);
 							} else if (fabs(rc.q[i] - P.model.q_lower[i]) < t.t2_angle) {
 								dir = 1;
-								if (do_torque) st(S, 26 + i, B, b, dir);
+								if (do_torque) st(S, MFT_T2DIR + i, B, b, dir);
 							}
 						}
 						t2dir[i] = dir;

@@ -525,12 +525,12 @@ SAI2B_TASK_FN void mft_task_g(const DevParams& P, const DevTask& t, const Rob& r
 		real qprior;  // this lane's component
 		if (commit_sh && (prev_types == 0 || c2 > c1)) {
 			if (rN) {
-				st(S, 12 + rs, B, b, rb.q);
-				st(S, 19 + rs, B, b, rb.dq);
+				st(S, MFT_QPRIOR + rs, B, b, rb.q);
+				st(S, MFT_DQPRIOR + rs, B, b, rb.dq);
 			}
 			qprior = rb.q;
 		} else {
-			qprior = ld(S, 12 + rs, B, b);
+			qprior = ld(S, MFT_QPRIOR + rs, B, b);
 		}
 		real us0[6], vs0 = 0, pv[N];
 		UNROLL for (int j = 0; j < N; j++) pv[j] = 0;
@@ -661,14 +661,14 @@ SAI2B_TASK_FN void mft_task_g(const DevParams& P, const DevTask& t, const Rob& r
 					const real y7 = mv<G, N>(ljMod, ut);
 					tau_j = mv<G, N>(bmT, y7);
 				} else {
-					real dir = ld(S, 26 + rs, B, b);
+					real dir = ld(S, MFT_T2DIR + rs, B, b);
 					if (rN && vs0 != 0) {
 						if (fabs(rb.q - P.model.q_upper[rs]) < t.t2_angle) {
 							dir = -1;
-							if (do_torque) st(S, 26 + rs, B, b, dir);
+							if (do_torque) st(S, MFT_T2DIR + rs, B, b, dir);
 						} else if (fabs(rb.q - P.model.q_lower[rs]) < t.t2_angle) {
 							dir = 1;
-							if (do_torque) st(S, 26 + rs, B, b, dir);
+							if (do_torque) st(S, MFT_T2DIR + rs, B, b, dir);
 						}
 					}
 					real Fs[6], nrm = 0, fTd = 0;

@@ -652,7 +652,7 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 		if ((rc = dev_alloc(ctx, &d.otg_desired, goal_rows * Bs))) return rc;
 		if ((rc = dev_alloc(ctx, &d.otg_state, (size_t)sai2b::OTG_ROWS * Bs))) return rc;
 		d.otg_epoch = 0.0;
-		d.otg_out_is_desired = (tasks[t].type == SAI2B_JOINT_TASK && d.k0 == N) ? 1 : 0;
+		d.otg_out_is_desired = (tasks[t].type == SAI2B_JOINT_TASK && d.k0 == N && N == sai2b::OTG_MD) ? 1 : 0;  // same row stride
 		d.law_goals = d.otg_on ? (d.otg_out_is_desired ? d.otg_state + (size_t)sai2b::OTG_OUT * Bs : d.otg_desired) : d.goals;
 	}
 	for (int t = 0; t < n_tasks; t++)
@@ -1340,7 +1340,7 @@ extern "C" int sai2b_set_mft_type1_posture(sai2b_ctx* ctx, int task, const doubl
 	int rc = mft_task_check(ctx, task, "sai2b_set_mft_type1_posture");
 	if (rc) return rc;
 	if (!q_des) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_set_mft_type1_posture: null posture");
-	return copy_rows(ctx, ctx->h_params.task[task].state + 12 * (size_t)ctx->B, q_des, N, on_device);
+	return copy_rows(ctx, ctx->h_params.task[task].state + (size_t)sai2b::MFT_QPRIOR * ctx->B, q_des, N, on_device);
 }
 extern "C" int sai2b_get_mft_status(sai2b_ctx* ctx, int task, double* pos, double* rot, double* sensed_force_world,
 									double* sensed_moment_world, double* pos_error, double* ori_error, double* pos_error_norm,

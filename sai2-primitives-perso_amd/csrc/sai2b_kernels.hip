@@ -269,9 +269,9 @@ __global__ __launch_bounds__(64) void reinit_kernel(const DevParams* __restrict_
 			for (int k = 0; k < 6; k++) st(tk.sensed, k, B, b, 0.0);
 			for (int k = 0; k < 12; k++) st(tk.state, k, B, b, 0.0);
 			UNROLL for (int i = 0; i < N; i++) {
-				st(tk.state, 12 + i, B, b, 0.5 * (P.model.q_lower[i] + P.model.q_upper[i]));
-				st(tk.state, 19 + i, B, b, 0.0);
-				st(tk.state, 26 + i, B, b, 1.0);
+				st(tk.state, MFT_QPRIOR + i, B, b, 0.5 * (P.model.q_lower[i] + P.model.q_upper[i]));
+				st(tk.state, MFT_DQPRIOR + i, B, b, 0.0);
+				st(tk.state, MFT_T2DIR + i, B, b, 1.0);
 			}
 			for (int k = 0; k < MFT_ISTATE_ROWS; k++) sti(tk.istate, k, B, b, 0);
 		} else {

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(64) void otg_reinit_kernel(const DevParams* __restr
 				if (mode == 1) {
 					real cur[N];
 					mv<N, N>(tk.S, q, cur);
-					UNROLL for (int d = 0; d < MD; d++) x0[d] = d < n ? cur[d] : 0.0;
+					UNROLL for (int d = 0; d < MD; d++) x0[d] = (d < n && d < N) ? cur[d < N ? d : 0] : 0.0;
 				} else {
 					load7(tk.goals, 0, n, B, b, x0);
 				}

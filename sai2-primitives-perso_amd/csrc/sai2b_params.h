@@ -114,7 +114,10 @@ constexpr int OTG_IN_SYNC = OTG_CART + 21;
 constexpr int OTG_ACTIVE = OTG_CART + 22;  // gated JointTask only: 1 = the task has a non-empty range this tick
 constexpr int OTG_ROWS = OTG_CART + 23;
 static_assert(N > 7 || (OTG_TRAJ == 99 && OTG_CART == 190 && OTG_IN_SYNC == 211), "row layout of the 7-DoF builds");
-constexpr int MFT_STATE_ROWS = 33;
+// rows of a MotionForceTask's state: integrators pos 3 ori 3 force 3 moment 3, then per joint q_prior, dq_prior and the
+// type-2 direction (SingularityHandler.h:218,227)
+constexpr int MFT_QPRIOR = 12, MFT_DQPRIOR = 12 + N, MFT_T2DIR = 12 + 2 * N;
+constexpr int MFT_STATE_ROWS = 12 + 3 * N;
 constexpr int MFT_ISTATE_ROWS = 12;
 constexpr int POPC_RING = 1024;	 // capacity of the PO window ring (the reference queue is unbounded)
 constexpr int POPC_WINDOW = 250, POPC_MAX_COUNTER = 50;	 // POPCExplicitForceControl.h:38-39

@@ -1,0 +1,118 @@
+"""Robots other than the 7-joint Panda on the GPU (-m gpu): the 8-joint Panda on a prismatic
+base with the hierarchy of examples/06-partial_joint_task/06-partial_joint_task.cpp:107-125 ([partial JointTask on
+the slider and the last joint, MotionForceTask, full JointTask]) and the planar 4R with the planar MotionForceTask
+of examples/11-planar_robot_controller/11-planar_robot_controller.cpp:108-125 (+ JointTask), against the CPU oracle
+built for that robot size. The models themselves are pinned against an independent numpy reading of the URDFs in
+tests/test_urdf.py."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import sai2_primitives_perso_amd as pkg
+
+import robots
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _err(a, ref):
+    return np.abs(a - ref).max(axis=0) / np.maximum(np.abs(ref).max(axis=0), 1.0)
+
+
+def _setup(robot, B, otg, introspection, seed=0):
+    m, links = pkg.model_from_urdf(robots.TEXT[robot](), is_file=False)
+    n = m.dof
+    rng = np.random.default_rng(100 + seed)
+    lo, hi = np.array(list(m.q_lower)[:n]), np.array(list(m.q_upper)[:n])
+    mid, half = 0.5 * (lo + hi), 0.5 * (hi - lo)
+    q = mid[:, None] + 0.6 * half[:, None] * rng.uniform(-1, 1, (n, B))
+    dq = rng.normal(0, 0.2, (n, B))
+    if robot == "sliding_base":
+        link, fpos, frot = pkg.resolve_link_frame(links, "end-effector", (0.0, 0.0, 0.07))
+        sel = np.zeros((2, n))
+        sel[0, 0] = sel[1, 7] = 1
+        mk = lambda mod, cfg_j, cfg_m: [cfg_j("partial_joint_task", sel, internal_otg=otg, robot_dof=n),
+                                        cfg_m("motion_force_task", link, fpos, frot, internal_otg=otg, robot_dof=n),
+                                        cfg_j("joint_task", None, internal_otg=otg, robot_dof=n)]
+        kinds = ["jt", "mft", "jt"]
+    else:
+        link, fpos, frot = pkg.resolve_link_frame(links, "link4", (0.5, 0.0, 0.0))
+        partial = (np.array([[1.0, 0, 0], [0, 1.0, 0]]), np.array([[0, 0, 1.0]]))
+        mk = lambda mod, cfg_j, cfg_m: [cfg_m("motion_force_task", link, fpos, frot, partial, internal_otg=otg, robot_dof=n),
+                                        cfg_j("joint_task", None, internal_otg=otg, robot_dof=n)]
+        kinds = ["mft", "jt"]
+    o = ol.Oracle(m, mk(ol, ol.joint_task, ol.motion_force_task), B, threads=8)
+    g = pkg.Controller(m, mk(pkg, pkg.joint_task_config, pkg.motion_force_task_config), B, introspection=introspection)
+    for c in (o, g):
+        c.set_state(q, dq)
+        c.reinitialize()
+    # goals around the current pose
+    for t, k in enumerate(kinds):
+        if k == "mft":
+            st = o.get_mft_status(t)
+            pos = st["pos"] + rng.uniform(-0.04, 0.04, (3, B))
+            if robot == "planar_4r":
+                pos[2] = st["pos"][2]
+                ax = np.tile(np.array([0, 0, 1.0]), (B, 1))
+            else:
+                ax = rng.normal(size=(B, 3))
+                ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+            R = st["rot"].T.reshape(B, 3, 3) @ pkg.workloads._expmap(ax * rng.uniform(0, 0.2, (B, 1)))
+            v = rng.normal(0, 0.03, (3, B)) * (1 if robot != "planar_4r" else np.array([[1], [1], [0]]))
+            for c in (o, g):
+                c.set_mft_goals(t, pos, np.ascontiguousarray(R.reshape(B, 9).T), v, None, None, None)
+        else:
+            k0 = o.tasks[t].task_dof
+            S = np.array(o.tasks[t].joint_selection[: k0 * n]).reshape(k0, n)
+            goal = S @ q + rng.normal(0, 0.1, (k0, B))
+            for c in (o, g):
+                c.set_jt_goals(t, goal, None, None)
+    return m, kinds, o, g, q, dq
+
+
+@pytest.mark.parametrize("introspection", [True, False])
+@pytest.mark.parametrize("otg", [False, True])
+@pytest.mark.parametrize("robot", list(robots.TEXT))
+def test_other_robots_match_the_oracle_in_closed_loop(robot, otg, introspection):
+    """10 control periods through the simulation harness: torques every period, joint states at the end;
+    introspection on = the one-lane-per-robot kernels, off = the lanes-per-robot generic kernel"""
+    B = 192
+    m, kinds, o, g, q, dq = _setup(robot, B, otg, introspection)
+    n = m.dof
+    if introspection:
+        g.tick(), o.tick()
+        assert np.abs(g.get_model() - o.get_model()).max() < 1e-11 * np.abs(o.get_model()).max()
+    for period in range(10):
+        tau_o, tau_g = o.tick(), g.tick()
+        assert tau_g.shape == (n, B)
+        singular = np.zeros(B, dtype=bool)
+        for t, k in enumerate(kinds):
+            if k == "mft":
+                _, _, ro = o.get_mft_singularity(t)
+                singular |= ro < (o.tasks[t].pos_range + o.tasks[t].ori_range)
+        e = _err(tau_g, tau_o)
+        assert e[~singular].max() < 1e-9, (period, e[~singular].max())
+        if singular.any():
+            assert e[singular].max() < 1e-5
+        for c in (o, g):
+            c.sim_step(tau_o, 0.001, 1, with_gravity=False)
+    qo, vo = o.get_state()
+    qg, vg = g.get_state()
+    assert np.abs(qo - qg).max() < 1e-10 and np.abs(vo - vg).max() < 1e-8
+
+
+@pytest.mark.parametrize("robot", list(robots.TEXT))
+def test_other_robots_gravity_bias_and_task_level_calls(robot):
+    B = 64
+    m, kinds, o, g, q, dq = _setup(robot, B, False, False, seed=3)
+    n = m.dof
+    for c in (o, g):
+        c.enable_gravity_compensation(True)
+    assert _err(g.tick(), o.tick()).max() < 1e-9
+    assert np.abs(g.get_bias(True) - o.get_bias(True)).max() < 1e-10 * max(1.0, np.abs(o.get_bias(True)).max())
+    # the TemplateTask-level calls on the first task
+    for c in (o, g):
+        c.task_update_model(0, None)
+    assert np.abs(g.task_nullspaces(0)[2] - o.task_nullspaces(0)[2]).max() < 1e-9
+    assert _err(g.task_compute_torques(0), o.task_compute_torques(0)).max() < 1e-9
