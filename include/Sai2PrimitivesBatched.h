@@ -62,11 +62,15 @@ public:
 		if (batch < 1) throw std::invalid_argument("BatchedRobotModel: batch must be >= 1");
 		detail::check(nullptr, sai2b_panda_model(&_model));
 	}
-	BatchedRobotModel(int batch, const sai2b_robot_model& model, int device = 0) : BatchedRobotModel(batch, device) { _model = model; }
+	BatchedRobotModel(int batch, const sai2b_robot_model& model, int device = 0) : BatchedRobotModel(batch, device) {
+		_model = model;
+		resizeState();
+	}
 	// Sai2Model::Sai2Model(urdf_file) (examples/05-...cpp:96-97): the robot description from a URDF file
 	BatchedRobotModel(const std::string& urdf_file, int batch, int device = 0) : BatchedRobotModel(batch, device) {
 		detail::check(nullptr, sai2b_model_from_urdf(urdf_file.c_str(), 1, &_model, &_links));
 		_has_links = true;
+		resizeState();	// 4, 6, 7 or 8 joints
 	}
 	// link name + compliant frame in that link (what the reference's task constructors take) -> moving link
 	// index and frame in it; the name may be a body behind fixed joints, e.g. "end-effector"
@@ -77,7 +81,7 @@ public:
 		detail::check(nullptr, sai2b_urdf_resolve_frame(&_links, link_name.c_str(), pos_in_link, rot_in_link, &link, frame_pos, frame_rot));
 		return link;
 	}
-	int dof() const { return SAI2B_DOF; }
+	int dof() const { return _model.dof; }
 	int batch() const { return _batch; }
 	int device() const { return _device; }
 	const sai2b_robot_model& model() const { return _model; }
@@ -93,8 +97,12 @@ private:
 	friend class RobotController;
 	friend class TemplateTask;
 	void assign(Batch& dst, const Batch& src) {
-		if (src.size() != dst.size()) throw std::invalid_argument("state must have 7 * batch entries ([7][B])");
+		if (src.size() != dst.size()) throw std::invalid_argument("state must have dof * batch entries ([dof][B])");
 		dst = src;
+	}
+	void resizeState() {
+		_q.assign((size_t)_model.dof * _batch, 0.0);
+		_dq.assign((size_t)_model.dof * _batch, 0.0);
 	}
 	std::vector<sai2b_ctx*> _standalone;  // contexts of tasks driven on their own (TemplateTask-level calls)
 	int _batch, _device;
@@ -118,7 +126,7 @@ public:
 	// caller chains the nullspaces as in examples/04-task_and_redundancy.cpp:141-150,188-189.
 	// N_prec: [49][B] row-major inside the component index (TemplateTask.h:42)
 	void updateTaskModel(const Batch& N_prec) {
-		checkRows(N_prec, 49, "N_prec");
+		checkRows(N_prec, (size_t)_robot->dof() * _robot->dof(), "N_prec");
 		detail::check(ctx(), sai2b_task_update_model(ctx(), index(), N_prec.data(), 0));
 		_task_level = true;
 	}
@@ -129,14 +137,14 @@ public:
 	}
 	// this task's torques [7][B] (TemplateTask.h:49)
 	Batch computeTorques() {
-		Batch tau(7 * B());
+		Batch tau((size_t)_robot->dof() * B());
 		detail::check(ctx(), sai2b_task_compute_torques(ctx(), index(), nullptr, tau.data(), 0));
 		return tau;
 	}
 	// with the feed-forward compensation of the previous tasks' torques (TemplateTask.h:58)
 	Batch computeTorques(const Batch& tau_prec) {
-		checkRows(tau_prec, 7, "tau_prec");
-		Batch tau(7 * B());
+		checkRows(tau_prec, _robot->dof(), "tau_prec");
+		Batch tau((size_t)_robot->dof() * B());
 		detail::check(ctx(), sai2b_task_compute_torques(ctx(), index(), tau_prec.data(), tau.data(), 0));
 		return tau;
 	}
@@ -169,7 +177,7 @@ protected:
 	inline sai2b_ctx* ctx() const;
 	int index() const { return _owner ? _index : 0; }
 	Batch nullspace(int which) const {
-		Batch out(49 * B());
+		Batch out((size_t)_robot->dof() * _robot->dof() * B());
 		double* p[3] = {nullptr, nullptr, nullptr};
 		p[which] = out.data();
 		detail::check(ctx(), sai2b_task_get_nullspaces(ctx(), index(), p[0], p[1], p[2]));
@@ -203,19 +211,19 @@ public:
 	// JointTask.h:56-58 (full) — JointTask.cpp:14-21
 	JointTask(std::shared_ptr<BatchedRobotModel>& robot, const std::string& task_name = "joint_task", const double loop_timestep = 0.001)
 		: TemplateTask(robot, JOINT_TASK) {
-		detail::check(nullptr, sai2b_default_joint_task(&_cfg, task_name.c_str(), 0, nullptr));
+		detail::check(nullptr, sai2b_default_joint_task_dof(&_cfg, task_name.c_str(), robot->dof(), 0, nullptr));
 		_cfg.loop_timestep = loop_timestep;
 	}
-	// JointTask.h:72-75 (partial; selection is row-major task_dof x 7) — JointTask.cpp:23-43
+	// JointTask.h:72-75 (partial; selection is row-major task_dof x dof) — JointTask.cpp:23-43
 	JointTask(std::shared_ptr<BatchedRobotModel>& robot, const std::vector<double>& joint_selection_matrix, const int task_dof,
 			  const std::string& task_name = "partial_joint_task", const double loop_timestep = 0.001)
 		: TemplateTask(robot, JOINT_TASK) {
-		if (task_dof < 1 || joint_selection_matrix.size() != (size_t)task_dof * SAI2B_DOF)
+		if (task_dof < 1 || joint_selection_matrix.size() != (size_t)task_dof * robot->dof())
 			throw std::invalid_argument("joint selection matrix size not consistent with robot dof in JointTask constructor\n");
-		detail::check(nullptr, sai2b_default_joint_task(&_cfg, task_name.c_str(), task_dof, joint_selection_matrix.data()));
+		detail::check(nullptr, sai2b_default_joint_task_dof(&_cfg, task_name.c_str(), robot->dof(), task_dof, joint_selection_matrix.data()));
 		_cfg.loop_timestep = loop_timestep;
 	}
-	bool isFullJointTask() const { return _cfg.task_dof == SAI2B_DOF; }
+	bool isFullJointTask() const { return _cfg.task_dof == _robot->dof(); }
 	int getTaskDof() const { return _cfg.task_dof; }
 	// JointTask.h:137-179; [task_dof][B]
 	void setGoalPosition(const Batch& v) {
@@ -236,7 +244,7 @@ public:
 	// JointTask.h:234-259
 	void setGains(const double kp, const double kv, const double ki = 0) {
 		if (kp < 0 || kv < 0 || ki < 0) throw std::invalid_argument("gains must be positive or zero in JointTask::setGains\n");
-		for (int i = 0; i < SAI2B_DOF; i++) _cfg.kp[i] = kp, _cfg.kv[i] = kv, _cfg.ki[i] = ki;
+		for (int i = 0; i < SAI2B_MAX_DOF; i++) _cfg.kp[i] = kp, _cfg.kv[i] = kv, _cfg.ki[i] = ki;
 		syncConfig();
 	}
 	std::vector<PIDGains> getGains() const {
@@ -247,7 +255,7 @@ public:
 	void enableVelocitySaturation(const double saturation_velocity) {
 		if (saturation_velocity <= 0) throw std::invalid_argument("saturation velocity must be positive in JointTask::enableVelocitySaturation\n");
 		_cfg.use_velocity_saturation = 1;
-		for (int i = 0; i < SAI2B_DOF; i++) _cfg.saturation_velocity[i] = saturation_velocity;
+		for (int i = 0; i < SAI2B_MAX_DOF; i++) _cfg.saturation_velocity[i] = saturation_velocity;
 		syncConfig();
 	}
 	void disableVelocitySaturation() {
@@ -263,7 +271,7 @@ public:
 			throw std::invalid_argument("max velocity cannot be 0 or negative in any directions in OTG_joints::setMaxVelocity\n");
 		if (max_acceleration <= 0)
 			throw std::invalid_argument("max acceleration cannot be 0 or negative in any directions in OTG_joints::setMaxAcceleration\n");
-		for (int i = 0; i < SAI2B_DOF; i++) _cfg.otg_max_velocity[i] = max_velocity, _cfg.otg_max_acceleration[i] = max_acceleration;
+		for (int i = 0; i < SAI2B_MAX_DOF; i++) _cfg.otg_max_velocity[i] = max_velocity, _cfg.otg_max_acceleration[i] = max_acceleration;
 		_cfg.use_internal_otg = 1, _cfg.internal_otg_jerk_limited = 0;
 		syncConfig();
 	}
@@ -305,8 +313,8 @@ public:
 					const double* compliant_frame_rot = nullptr, const std::string& task_name = "motion_force_task",
 					const bool is_force_motion_parametrization_in_compliant_frame = false, const double loop_timestep = 0.001)
 		: TemplateTask(robot, MOTION_FORCE_TASK) {
-		detail::check(nullptr, sai2b_default_motion_force_task(&_cfg, task_name.c_str(), link, compliant_frame_pos, compliant_frame_rot, -1,
-															   nullptr, -1, nullptr));
+		detail::check(nullptr, sai2b_default_motion_force_task_dof(&_cfg, task_name.c_str(), robot->dof(), link, compliant_frame_pos, compliant_frame_rot, -1,
+																   nullptr, -1, nullptr));
 		_cfg.parametrization_in_compliant_frame = is_force_motion_parametrization_in_compliant_frame;
 		_cfg.loop_timestep = loop_timestep;
 	}
@@ -317,7 +325,7 @@ public:
 		: TemplateTask(robot, MOTION_FORCE_TASK) {
 		double fp[3], fr[9];
 		const int link = robot->resolveLink(link_name, compliant_frame_pos, compliant_frame_rot, fp, fr);
-		detail::check(nullptr, sai2b_default_motion_force_task(&_cfg, task_name.c_str(), link, fp, fr, -1, nullptr, -1, nullptr));
+		detail::check(nullptr, sai2b_default_motion_force_task_dof(&_cfg, task_name.c_str(), robot->dof(), link, fp, fr, -1, nullptr, -1, nullptr));
 		_cfg.parametrization_in_compliant_frame = is_force_motion_parametrization_in_compliant_frame;
 		_cfg.loop_timestep = loop_timestep;
 	}
@@ -327,8 +335,8 @@ public:
 					const double* compliant_frame_rot = nullptr, const std::string& task_name = "partial_motion_force_task",
 					const bool is_force_motion_parametrization_in_compliant_frame = false, const double loop_timestep = 0.001)
 		: TemplateTask(robot, MOTION_FORCE_TASK) {
-		detail::check(nullptr, sai2b_default_motion_force_task(&_cfg, task_name.c_str(), link, compliant_frame_pos, compliant_frame_rot,
-															   (int)controlled_directions_translation.size() / 3, controlled_directions_translation.data(),
+		detail::check(nullptr, sai2b_default_motion_force_task_dof(&_cfg, task_name.c_str(), robot->dof(), link, compliant_frame_pos, compliant_frame_rot,
+																   (int)controlled_directions_translation.size() / 3, controlled_directions_translation.data(),
 															   (int)controlled_directions_rotation.size() / 3, controlled_directions_rotation.data()));
 		_cfg.parametrization_in_compliant_frame = is_force_motion_parametrization_in_compliant_frame;
 		_cfg.loop_timestep = loop_timestep;
@@ -506,7 +514,7 @@ public:
 	}
 	// MotionForceTask.h:706 -> SingularityHandler.h:140-142; q_des [7][B]
 	void setType1Posture(const Batch& q_des) {
-		checkRows(q_des, 7, "type 1 posture");
+		checkRows(q_des, _robot->dof(), "type 1 posture");
 		detail::check(ctx(), sai2b_set_mft_type1_posture(ctx(), index(), q_des.data(), 0));
 	}
 	// MotionForceTask.h:281-304: per-axis gains, with and without the sign check
@@ -637,13 +645,13 @@ public:
 	void updateControllerTaskModels() { detail::check(_ctx, sai2b_update_task_models(_ctx)); }
 	// [7][B]
 	Batch computeControlTorques() {
-		Batch tau(7 * (size_t)_robot->batch());
+		Batch tau((size_t)_robot->dof() * _robot->batch());
 		detail::check(_ctx, sai2b_compute_control_torques(_ctx, tau.data(), 0));
 		return tau;
 	}
 	// updateControllerTaskModels() + computeControlTorques() in one kernel launch
 	Batch tick() {
-		Batch tau(7 * (size_t)_robot->batch());
+		Batch tau((size_t)_robot->dof() * _robot->batch());
 		detail::check(_ctx, sai2b_tick(_ctx, tau.data(), 0));
 		return tau;
 	}
@@ -708,7 +716,7 @@ inline void TemplateTask::syncConfig() {
 }
 inline Batch TemplateTask::getTaskAndPreviousNullspace() const {
 	if (_task_level || !_owner) return nullspace(2);
-	Batch out(49 * B());
+	Batch out((size_t)_robot->dof() * _robot->dof() * B());
 	detail::check(_owner->ctx(), sai2b_get_task_nullspace(_owner->ctx(), _index, out.data()));
 	return out;
 }
@@ -731,6 +739,7 @@ public:
 		: BatchedSimulation(task.context(), timestep, substeps) {}
 	BatchedSimulation(sai2b_ctx* ctx, const double timestep, const int substeps) : _c(ctx), _dt(timestep), _substeps(substeps) {
 		if (timestep <= 0 || substeps < 1) throw std::invalid_argument("simulation timestep must be positive");
+		_dof = sai2b_num_joints(ctx);
 	}
 	void setTimestep(const double dt) {
 		if (dt <= 0) throw std::invalid_argument("simulation timestep must be positive");
@@ -744,6 +753,7 @@ public:
 
 private:
 	sai2b_ctx* _c;
+	int _dof = SAI2B_DOF;
 	double _dt;
 	int _substeps;
 	bool _gravity = false;
@@ -815,17 +825,17 @@ inline Batch MotionForceTask::getDesiredLinearAcceleration() const { return desi
 inline Batch MotionForceTask::getDesiredAngularAcceleration() const { return desired(5); }
 inline void BatchedSimulation::integrate() {
 	sai2b_ctx* c = _c;
-	if (!_tau.empty() && _tau.size() != 7 * (size_t)sai2b_batch(c)) throw std::invalid_argument("joint torques must have shape [7][B]");
+	if (!_tau.empty() && _tau.size() != (size_t)_dof * sai2b_batch(c)) throw std::invalid_argument("joint torques must have shape [dof][B]");
 	detail::check(c, sai2b_sim_step(c, _tau.empty() ? nullptr : _tau.data(), 0, _dt, _substeps, _gravity ? 1 : 0));
 	_tau.clear();
 }
 inline Batch BatchedSimulation::getJointPositions() const {
-	Batch q(7 * (size_t)sai2b_batch(_c));
+	Batch q((size_t)_dof * sai2b_batch(_c));
 	detail::check(_c, sai2b_get_state(_c, q.data(), nullptr));
 	return q;
 }
 inline Batch BatchedSimulation::getJointVelocities() const {
-	Batch dq(7 * (size_t)sai2b_batch(_c));
+	Batch dq((size_t)_dof * sai2b_batch(_c));
 	detail::check(_c, sai2b_get_state(_c, nullptr, dq.data()));
 	return dq;
 }

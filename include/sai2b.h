@@ -223,6 +223,7 @@ const char* sai2b_last_error(const sai2b_ctx* ctx);
 
 int sai2b_batch(const sai2b_ctx* ctx);
 int sai2b_num_tasks(const sai2b_ctx* ctx);
+int sai2b_num_joints(const sai2b_ctx* ctx); /* joints of the context's robot */
 
 /* Re-configure batch-uniform task parameters (gains, decoupling, force-space parametrisation,
  * flags) after creation — the reference's setters (MotionForceTask.h:272-328,576-623,669-753,
@@ -243,7 +244,7 @@ int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_task_config* 
 int sai2b_enable_gravity_compensation(sai2b_ctx* ctx, int enable);
 
 /* Sai2Model::setQ / setDq + updateModel (examples/05-using_robot_controller.cpp:143-145).
- * q, dq: [7][B]. on_device != 0 -> the pointers are device memory. */
+ * q, dq: [dof][B] (here and below "7" in a shape stands for the robot's dof). on_device != 0 -> the pointers are device memory. */
 int sai2b_set_state(sai2b_ctx* ctx, const double* q, const double* dq, int on_device);
 
 /* MotionForceTask::setGoalPosition/Orientation/LinearVelocity/AngularVelocity/

@@ -182,6 +182,7 @@ EXPORTS = [
     "sai2b_last_error",
     "sai2b_batch",
     "sai2b_num_tasks",
+    "sai2b_num_joints",
     "sai2b_update_task_config",
     "sai2b_enable_gravity_compensation",
     "sai2b_set_state",
@@ -268,6 +269,7 @@ def load_library():
     lib.sai2b_last_error.restype = C.c_char_p
     lib.sai2b_batch.argtypes = [vp]
     lib.sai2b_num_tasks.argtypes = [vp]
+    lib.sai2b_num_joints.argtypes = [vp]
     lib.sai2b_update_task_config.argtypes = [vp, _i, P(TaskConfig)]
     lib.sai2b_enable_gravity_compensation.argtypes = [vp, _i]
     lib.sai2b_set_state.argtypes = [vp, vp, vp, _i]

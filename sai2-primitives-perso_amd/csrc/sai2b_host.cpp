@@ -707,6 +707,7 @@ extern "C" void sai2b_destroy(sai2b_ctx* ctx) {
 extern "C" const char* sai2b_last_error(const sai2b_ctx* ctx) { return ctx ? ctx->error.c_str() : g_error.c_str(); }
 extern "C" int sai2b_batch(const sai2b_ctx* ctx) { return ctx ? ctx->B : 0; }
 extern "C" int sai2b_num_tasks(const sai2b_ctx* ctx) { return ctx ? ctx->T : 0; }
+extern "C" int sai2b_num_joints(const sai2b_ctx* ctx) { return ctx ? N : 0; }
 
 // `reset` of MotionForceTask::parametrizeForceMotionSpaces / parametrizeMomentRotMotionSpaces
 // (MotionForceTask.cpp:838-848,866-878): the dimension changed, or, for dimension 1 or 2, the normalised

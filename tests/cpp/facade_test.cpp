@@ -4,6 +4,7 @@
 //   facade_test tick <B> <in>   (GPU)    reads q,dq,goals (raw doubles) from <in>, prints torques
 //   facade_test example04 <B> <in> <ticks> / example01 <B> <in> <ticks>   (GPU) the reference's examples 04 and 01,
 //                               tasks driven through the TemplateTask virtuals with no RobotController
+//   facade_test example06 <B> <urdf> <in> <ticks>   (GPU) example 06: the 8-joint sliding-base Panda from its URDF
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -235,8 +236,67 @@ static int example01(int B, const char* path, int ticks) {
 	return 0;
 }
 
+// examples/06-partial_joint_task/06-partial_joint_task.cpp:99-176 call for call: the 8-joint Panda on its prismatic
+// base read from a URDF file, a partial JointTask on the slider and the last joint above a MotionForceTask, driven by a
+// RobotController; the schedule of the slider's goal steps compressed into `ticks` periods. (The partial task keeps
+// the reference's default internal OTG, whose next state the example feeds to the motion task.)
+static int example06(int B, const char* urdf, const char* path, int ticks) {
+	auto robot = std::make_shared<BatchedRobotModel>(std::string(urdf), B);
+	const int dof = robot->dof();
+	std::ifstream f(path, std::ios::binary);
+	Batch q0((size_t)dof * B), dq0((size_t)dof * B, 0.0);
+	f.read((char*)q0.data(), q0.size() * sizeof(double));
+	robot->setQ(q0);
+	robot->setDq(dq0);
+	robot->updateModel();  // :102
+	std::vector<double> joint_selection(2 * (size_t)dof, 0.0);	// :107-109
+	joint_selection[0] = 1;
+	joint_selection[(size_t)dof + 7] = 1;
+	auto partial_joint_task = std::make_shared<JointTask>(robot, joint_selection, 2);  // :110-111
+	const double pos_in_link[3] = {0.0, 0.0, 0.07};										// :116-117
+	auto motion_force_task = std::make_shared<MotionForceTask>(robot, std::string("end-effector"), pos_in_link);  // :118-119
+	motion_force_task->disableInternalOtg();																	   // :120
+	std::vector<std::shared_ptr<TemplateTask>> task_list = {partial_joint_task, motion_force_task};			   // :123-124
+	RobotController robot_controller(robot, task_list);															   // :125-126
+	Batch joint_goal_pos = partial_joint_task->getGoalPosition();  // :112 getCurrentPosition() at construction = the goal after it
+	const Batch initial_position = motion_force_task->getCurrentPosition();	 // :121
+	BatchedSimulation sim(robot_controller, 0.001, 2);						 // the example's 2 kHz simulation thread
+	for (int cycle = 0; cycle < ticks; cycle++) {
+		robot->setQ(sim.getJointPositions());  // :137-139
+		robot->setDq(sim.getJointVelocities());
+		robot->updateModel();
+		robot_controller.updateControllerTaskModels();	// :142
+		if (cycle % 40 == 10)							// :146-150
+			for (int b = 0; b < B; b++) joint_goal_pos[b] -= 1.0;
+		else if (cycle % 40 == 30)
+			for (int b = 0; b < B; b++) joint_goal_pos[b] += 1.0;
+		partial_joint_task->setGoalPosition(joint_goal_pos);  // :151
+		const double time = 0.001 * cycle, w = 2.0 * M_PI * 0.3;
+		const Batch dp = partial_joint_task->getDesiredPosition(), dv = partial_joint_task->getDesiredVelocity(),
+					da = partial_joint_task->getDesiredAcceleration();
+		Batch gp(3 * (size_t)B), gv(3 * (size_t)B), ga(3 * (size_t)B);
+		for (int b = 0; b < B; b++) {  // :154-166
+			gp[b] = initial_position[b] + 0.1 * std::sin(w * time);
+			gp[(size_t)B + b] = dp[b];
+			gp[2 * (size_t)B + b] = initial_position[2 * (size_t)B + b] + 0.1 * (1 - std::cos(w * time));
+			gv[b] = 0.1 * w * std::cos(w * time), gv[(size_t)B + b] = dv[b], gv[2 * (size_t)B + b] = 0.1 * w * std::sin(w * time);
+			ga[b] = -0.1 * w * w * std::sin(w * time), ga[(size_t)B + b] = da[b], ga[2 * (size_t)B + b] = 0.1 * w * w * std::cos(w * time);
+		}
+		motion_force_task->setGoalPosition(gp);	 // :167-169
+		motion_force_task->setGoalLinearVelocity(gv);
+		motion_force_task->setGoalLinearAcceleration(ga);
+		const Batch control_torques = robot_controller.computeControlTorques();	 // :174
+		std::fwrite(control_torques.data(), sizeof(double), control_torques.size(), stdout);
+		sim.integrate();
+	}
+	const Batch q1 = sim.getJointPositions();
+	std::fwrite(q1.data(), sizeof(double), q1.size(), stdout);
+	return 0;
+}
+
 int main(int argc, char** argv) {
 	try {
+		if (argc >= 6 && std::strcmp(argv[1], "example06") == 0) return example06(std::atoi(argv[2]), argv[3], argv[4], std::atoi(argv[5]));
 		if (argc >= 5 && std::strcmp(argv[1], "example04") == 0) return example04(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example01") == 0) return example01(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 2 && std::strcmp(argv[1], "validate") == 0) return validate();

@@ -157,3 +157,55 @@ def test_cpp_example_01_joint_control(facade_bin, tmp_path):
         assert _err(out[cycle], tau) < 1e-9, (cycle, _err(out[cycle], tau))
         o.sim_step(tau, 0.001, 1)
     assert np.abs(out[ticks] - o.get_state()[0]).max() < 1e-10
+
+
+@pytest.mark.gpu
+def test_cpp_example_06_partial_joint_task_on_the_sliding_base(facade_bin, tmp_path):
+    """tests/cpp/facade_test.cpp::example06 = examples/06-partial_joint_task.cpp:99-176 call for call: an 8-joint robot with
+    a prismatic base read from a URDF, RobotController over [partial JointTask (internal OTG on), MotionForceTask]"""
+    import oracle_lib as ol
+    import robots
+
+    B, ticks = 64, 60
+    urdf = tmp_path / "sliding_base.urdf"
+    urdf.write_text(robots.TEXT["sliding_base"]())
+    m, links = pkg.model_from_urdf(str(urdf))
+    n = m.dof
+    rng = np.random.default_rng(6)
+    lo, hi = np.array(list(m.q_lower)[:n]), np.array(list(m.q_upper)[:n])
+    q0 = (0.5 * (lo + hi))[:, None] + 0.5 * (0.5 * (hi - lo))[:, None] * rng.uniform(-1, 1, (n, B))
+    path = tmp_path / "q.bin"
+    q0.astype(np.float64).tofile(path)
+    r = subprocess.run([facade_bin, "example06", str(B), str(urdf), str(path), str(ticks)], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    out = np.frombuffer(r.stdout, dtype=np.float64).reshape(ticks + 1, n, B)
+    sel = np.zeros((2, n))
+    sel[0, 0] = sel[1, 7] = 1
+    link, fpos, frot = pkg.resolve_link_frame(links, "end-effector", (0.0, 0.0, 0.07))
+    cfg = [ol.joint_task("partial_joint_task", sel, internal_otg=True, robot_dof=n),
+           ol.motion_force_task("motion_force_task", link, fpos, frot, robot_dof=n)]
+    o = ol.Oracle(m, cfg, B, threads=8)
+    o.set_state(q0, np.zeros_like(q0))
+    o.reinitialize()
+    goal = o.get_jt_goals(0)[0] if hasattr(o, "get_jt_goals") else sel @ q0
+    x0 = o.get_mft_status(1)["pos"]
+    for cycle in range(ticks):
+        o.update_task_models()
+        if cycle % 40 == 10:
+            goal[0] -= 1.0
+        elif cycle % 40 == 30:
+            goal[0] += 1.0
+        o.set_jt_goals(0, goal)
+        t, w = 0.001 * cycle, 2.0 * np.pi * 0.3
+        dp, dv, da = o.get_jt_desired(0)
+        gp, gv, ga = np.empty((3, B)), np.empty((3, B)), np.empty((3, B))
+        gp[0], gp[1], gp[2] = x0[0] + 0.1 * np.sin(w * t), dp[0], x0[2] + 0.1 * (1 - np.cos(w * t))
+        gv[0], gv[1], gv[2] = 0.1 * w * np.cos(w * t), dv[0], 0.1 * w * np.sin(w * t)
+        ga[0], ga[1], ga[2] = -0.1 * w * w * np.sin(w * t), da[0], 0.1 * w * w * np.cos(w * t)
+        o.set_mft_goals(1, gp, None, gv, None, ga, None)
+        tau = o.compute_control_torques(True)
+        # the last joint belongs to the joint task above, so the 6-DOF motion task has lost a direction for every robot:
+        # it runs inside its singularity handling, where two FP64 implementations agree to ~1e-6
+        assert _err(out[cycle], tau) < 1e-6, (cycle, _err(out[cycle], tau))
+        o.sim_step(tau, 0.001, 2)
+    assert np.abs(out[ticks] - o.get_state()[0]).max() < 1e-7
