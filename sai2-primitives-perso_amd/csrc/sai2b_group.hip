@@ -56,7 +56,9 @@ extern "C" int sai2b_launch_tick_group(const sai2b::DevParams* d_params, int B, 
 									   int do_torque, const int* fb_count, const int* fb_list, hipStream_t stream) {
 	const int gpb = 64 / lanes;
 	int blocks = (B + gpb - 1) / gpb;
-	if (fb_count && blocks > 4096) blocks = 4096;
+	// the pass over a work list strides over it: one wavefront per SIMD is all this kernel can have resident (512
+	// registers), so more workgroups than SIMDs only add launch cost when the list is short, which it usually is
+	if (fb_count && blocks > 1024) blocks = 1024;
 	const dim3 grid(blocks), block(64);
 	if (lanes == 16) {
 		if (range_only)
