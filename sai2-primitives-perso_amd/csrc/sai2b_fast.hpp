@@ -1,8 +1,8 @@
 // sai2b_fast.hpp — SVD-free fast path of the tick for the hierarchies
 //     [full 6-DOF MotionForceTask]                        (BASELINE config 2)
 //     [full 6-DOF MotionForceTask, full JointTask]        (BASELINE configs 3 and 5)
-// taken by a wavefront only when EVERY one of its robots carries a certificate that the
-// SingularityHandler's decision is "fully non-singular" (SingularityHandler.cpp:100-141). In that
+// taken by a robot only when it carries a certificate that the SingularityHandler's decision is "fully
+// non-singular" (SingularityHandler.cpp:100-141). In that
 // branch the reference's result does not depend on the singular vectors at all:
 //     tau_mft = J^T ( (J Mb^-1 J^T)^-1 F_unit + F_force )            (U_ns cancels, :307-309)
 //     N       = I - M^-1 J^T (J M^-1 J^T)^-1 J  =  L^-T (w w^T) L^T   with M = L L^T, w ⟂ range(L^-1 J^T)
@@ -13,8 +13,9 @@
 // The singular values themselves are needed only for the branch decision, which is replaced by a
 // certificate on G = J J^T:  lambda_max(G) <= ub := tr(G^8)^(1/8) <= 6^(1/8) lambda_max(G), and
 // G - s_max^2 ub I positive definite  =>  s_5/s_0 >= s_max (and every s_i/s_0 with it).
-// Robots the certificate cannot vouch for (s_5/s_0 below ~0.067, or anything singular) make their
-// whole wavefront take the generic Jacobi-SVD path, so the results are the reference's in all cases.
+// A robot the certificate cannot vouch for (s_5/s_0 below ~0.067, or anything singular) touches no state here
+// and is appended to a work list (one atomic per wavefront that has such robots); the generic kernel launched
+// right behind runs over that compacted list, so the results are the reference's in all cases.
 #pragma once
 #include "sai2b_device.hpp"
 
