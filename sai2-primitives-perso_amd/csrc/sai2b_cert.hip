@@ -1,0 +1,43 @@
+// sai2b_cert.hip — the SVD-free tick for general hierarchies (sai2b_cert.hpp), one lane per robot: what runs
+// first for every hierarchy outside [full MFT(, full JT)]; the robots it declines go to the lanes-per-robot
+// generic kernel (sai2b_group.hip) through the same work list as behind tick_fast_kernel.
+#include <hip/hip_runtime.h>
+
+#include "sai2b_cert.hpp"
+#include "sai2b_launch.h"
+
+namespace sai2b {
+
+// fb_counts / fb_list / parity: as tick_fast_kernel (sai2b_kernels.hip)
+__global__ __launch_bounds__(64) void tick_cert_kernel(const DevParams* __restrict__ Pp, int with_comp, int* __restrict__ fb_counts,
+													  int* __restrict__ fb_list, int parity) {
+	__shared__ real pend_lds[cert::PEND_SLOTS * 64];
+	const DevParams& P = *Pp;
+	const int B = P.B;
+	const int b = blockIdx.x * 64 + threadIdx.x;
+	if (blockIdx.x == 0 && threadIdx.x == 0) ((gint*)fb_counts)[1 - parity] = 0;
+	if (b >= B) return;
+	real* pend = pend_lds + threadIdx.x;
+	real tau[N];
+	const bool mine = cert::tick(P, B, b, with_comp != 0, pend, tau);
+	const unsigned long long declined = __ballot(!mine);
+	if (declined) {
+		int base = 0;
+		if (threadIdx.x == 0) base = atomicAdd(&fb_counts[parity], __popcll(declined));	 // lane 0 is always in range
+		base = __shfl(base, 0);
+		if (!mine) {
+			((gint*)fb_list)[base + __popcll(declined & ((1ull << threadIdx.x) - 1ull))] = b;
+			return;
+		}
+	}
+	cert::flush(P, B, b, pend);
+	UNROLL for (int i = 0; i < N; i++) st(P.tau, i, B, b, tau[i] + pend[i * 64]);  // RobotController.cpp:70-72
+}
+
+}  // namespace sai2b
+
+extern "C" int sai2b_launch_tick_cert(const sai2b::DevParams* d_params, int B, int with_comp, int* fb_counts, int* fb_list, int parity,
+									  hipStream_t stream) {
+	hipLaunchKernelGGL(sai2b::tick_cert_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, d_params, with_comp, fb_counts, fb_list, parity);
+	return (int)hipGetLastError();
+}

@@ -35,6 +35,7 @@ struct sai2b_ctx {
 	bool params_dirty = true;
 	bool baked_model = false;  // the ctx model is bit-equal to the compile-time Panda constants
 	bool no_fast_path = false;	// SAI2B_NO_FAST_PATH=1 in the environment: always run the generic kernel
+	bool no_cert_path = false;	// SAI2B_NO_CERT_PATH=1: no SVD-free kernel for general hierarchies (sai2b_cert.hpp)
 	// lanes per robot of the generic kernel: SAI2B_GENERIC_LANES = 16 / 8 / 1 (1: the one-lane-per-robot kernel),
 	// default 0 = by the amount of work (generic_lanes())
 	int generic_lanes_env = 0;
@@ -605,6 +606,8 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	ctx->model = *model;
 	const char* nf = std::getenv("SAI2B_NO_FAST_PATH");
 	ctx->no_fast_path = nf && nf[0] == '1';
+	const char* nc = std::getenv("SAI2B_NO_CERT_PATH");
+	ctx->no_cert_path = nc && nc[0] == '1';
 	if (const char* gl = std::getenv("SAI2B_GENERIC_LANES")) ctx->generic_lanes_env = std::atoi(gl);
 	DevParams& hp = ctx->h_params;
 	std::memset(&hp, 0, sizeof(hp));
@@ -915,18 +918,37 @@ extern "C" int sai2b_reinitialize(sai2b_ctx* ctx) {
 
 // eligibility of the SVD-free path (sai2b_fast.hpp): [full MFT] or [full MFT, full JT] (any batch size: a robot
 // the kernel declines goes to the generic kernel on its own, lanes past the batch just exit)
+// 3: the SVD-free kernel for general hierarchies (sai2b_cert.hpp): any robot size and joint type, any sequence of
+// tasks whose rows can all be independent (at most N of them, a full JointTask only at the bottom)
+static int cert_kind(const sai2b_ctx* ctx) {
+	if (ctx->no_fast_path || ctx->no_cert_path || ctx->T < 1) return 0;
+	int rows = 0, slots = N;  // deferred stores per robot (sai2b_cert.hpp: PEND_SLOTS = 48)
+	for (int t = 0; t < ctx->T; t++) {
+		const DevTask& d = ctx->h_params.task[t];
+		if (d.type == SAI2B_MOTION_FORCE_TASK) {
+			// the passivity observer mutates per-robot state inside the law: generic kernel only
+			if (ctx->cfg[t].passivity_enabled && ctx->cfg[t].closed_loop_force) return 0;
+			rows += d.rank;
+			slots += 12;
+		} else {
+			if (d.full_selection && t != ctx->T - 1) return 0;
+			rows += d.full_selection ? 0 : d.k0;
+			slots += d.k0;
+		}
+	}
+	return (rows <= N && slots <= 48) ? 3 : 0;
+}
 static int fast_kind(const sai2b_ctx* ctx) {
-	// the SVD-free kernels are written for 7 revolute joints (a 6-DOF task leaves a one-dimensional nullspace)
-	if (N != 7) return 0;
+	// these two kernels are written for 7 revolute joints (a 6-DOF task leaves a one-dimensional nullspace)
+	bool arm7 = N == 7;
 	for (int i = 0; i < N; i++)
-		if (ctx->model.joint_type[i] != SAI2B_REVOLUTE) return 0;
-	// the passivity observer mutates per-robot state inside the law: generic kernel only
-	if (ctx->cfg[0].passivity_enabled && ctx->cfg[0].closed_loop_force) return 0;
-	if (ctx->no_fast_path || ctx->T > 2 || ctx->cfg[0].type != SAI2B_MOTION_FORCE_TASK ||
-		!ctx->h_params.task[0].full_projection || ctx->h_params.task[0].rank != 6)
-		return 0;
+		if (ctx->model.joint_type[i] != SAI2B_REVOLUTE) arm7 = false;
+	if (!arm7 || ctx->no_fast_path || ctx->T > 2 || ctx->cfg[0].type != SAI2B_MOTION_FORCE_TASK ||
+		!ctx->h_params.task[0].full_projection || ctx->h_params.task[0].rank != 6 ||
+		(ctx->cfg[0].passivity_enabled && ctx->cfg[0].closed_loop_force))
+		return cert_kind(ctx);
 	if (ctx->T == 1) return 1;
-	return (ctx->cfg[1].type == SAI2B_JOINT_TASK && ctx->h_params.task[1].full_selection) ? 2 : 0;
+	return (ctx->cfg[1].type == SAI2B_JOINT_TASK && ctx->h_params.task[1].full_selection) ? 2 : cert_kind(ctx);
 }
 
 // How many lanes a robot gets in the generic kernel (sai2b_group.hip). 16 = one DPP row per robot: the shortest

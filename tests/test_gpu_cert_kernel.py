@@ -1,0 +1,71 @@
+"""The SVD-free kernel for general hierarchies (sai2b_cert.hip: one lane per robot, whitened cascade) — what a
+tick() runs first for every hierarchy outside [full MFT(, full JT)] — against the CPU oracle and the golden
+fixtures: 1e-10 per robot it keeps; the robots it declines (singular, near-singular, rank-deficient levels) must
+come out of the generic kernel behind it with the same guarantees as before, and it must KEEP the regular ones."""
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as ol
+import robots
+import sai2_primitives_perso_amd as pkg
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _err(tau, ref):
+    return np.abs(tau - ref).max(axis=0) / np.maximum(np.abs(ref).max(axis=0), 1.0)
+
+
+def _pair(inp, opts=None, model=None, omodel=None):
+    go, gg = ol.task_configs(inp["tasks"]), pkg.task_configs(inp["tasks"])
+    for cfgs in (go, gg):
+        for c, o in zip(cfgs, opts or []):
+            cases.apply_opts(c, o)
+    return (ol.Oracle(omodel or ol.panda_model(), go, inp["B"], threads=8),
+            pkg.Controller(model or pkg.panda_model(), gg, inp["B"]))
+
+
+def _singular(o, inp):
+    s = np.zeros(inp["B"], dtype=bool)
+    for t, (kind, _) in enumerate(inp["tasks"]):
+        if kind == "mft":
+            _, _, ro = o.get_mft_singularity(t)
+            s |= ro < (o.tasks[t].pos_range + o.tasks[t].ori_range)
+    return s
+
+
+@pytest.mark.parametrize("name", list(cases.case_table()))
+def test_cert_kernel_on_golden_cases(name):
+    inp, opts, kw, z = cases.load_case(name)
+    o, g = _pair(inp, opts)
+    tau_o = cases.run_case_on(o, inp, kw, z)
+    tau_g = cases.run_case_on(g, inp, kw, z)
+    sing = _singular(o, inp)
+    e = _err(tau_g, tau_o)
+    assert e[~sing].max() < TOL, e[~sing].max()
+    if sing.any():
+        assert e[sing].max() < 1e-6
+    assert _err(tau_g, z["out_tau"])[~sing].max() < TOL
+
+
+@pytest.mark.parametrize("decoupling", [0, 1, 2])
+def test_cert_kernel_c4_hierarchy_keeps_regular_robots(decoupling):
+    """[MFT(3), JT(2), JT(7)] (BASELINE config 4), every decoupling type, integral gains on so that the state
+    the kernel holds back until a robot is known to finish in it is visible in the torques of the next ticks:
+    per-robot parity over three ticks, and the kernel keeps what is regular"""
+    B = 4096 + 37
+    inp = pkg.workloads.make_inputs(4, B=B, seed=4100 + decoupling)
+    opts = [{"decoupling": decoupling, "ki": 40.0, "ki_pos": 40.0, "ki_ori": 40.0} for _ in inp["tasks"]]
+    o, g = _pair(inp, opts)
+    ol.load_inputs(o, inp)
+    ol.load_inputs(g, inp)
+    for tick in range(3):
+        tau_o, tau_g = o.tick(), g.tick()
+        sing = _singular(o, inp)
+        e = _err(tau_g, tau_o)
+        assert e[~sing].max() < TOL, (tick, e[~sing].max())
+        assert e.max() < 1e-6
+        # declined: the singular robots and a margin of near-singular ones (the certificate is sufficient, not necessary)
+        assert sing.sum() <= g.fallback_count() <= sing.sum() + B // 20, (g.fallback_count(), sing.sum())
