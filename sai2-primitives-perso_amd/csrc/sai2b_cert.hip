@@ -8,10 +8,13 @@
 
 namespace sai2b {
 
-// fb_counts / fb_list / parity: as tick_fast_kernel (sai2b_kernels.hip)
+// fb_counts / fb_list / parity: as tick_fast_kernel (sai2b_kernels.hip). MCAP: most rows a partial task of the
+// hierarchy brings; the instantiation for small tasks (position-only MotionForceTask, a few selected joints) does
+// not carry the register footprint of a 6- or 7-row level.
+template <int MCAP>
 __global__ __launch_bounds__(64) void tick_cert_kernel(const DevParams* __restrict__ Pp, int with_comp, int* __restrict__ fb_counts,
 													  int* __restrict__ fb_list, int parity) {
-	__shared__ real pend_lds[cert::PEND_SLOTS * 64];
+	__shared__ real pend_lds[cert::LDS_SLOTS * 64];
 	const DevParams& P = *Pp;
 	const int B = P.B;
 	const int b = blockIdx.x * 64 + threadIdx.x;
@@ -19,7 +22,7 @@ __global__ __launch_bounds__(64) void tick_cert_kernel(const DevParams* __restri
 	if (b >= B) return;
 	real* pend = pend_lds + threadIdx.x;
 	real tau[N];
-	const bool mine = cert::tick(P, B, b, with_comp != 0, pend, tau);
+	const bool mine = cert::tick<MCAP, cert::DM>(P, B, b, with_comp != 0, pend, tau);
 	const unsigned long long declined = __ballot(!mine);
 	if (declined) {
 		int base = 0;
@@ -36,8 +39,12 @@ __global__ __launch_bounds__(64) void tick_cert_kernel(const DevParams* __restri
 
 }  // namespace sai2b
 
-extern "C" int sai2b_launch_tick_cert(const sai2b::DevParams* d_params, int B, int with_comp, int* fb_counts, int* fb_list, int parity,
-									  hipStream_t stream) {
-	hipLaunchKernelGGL(sai2b::tick_cert_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, d_params, with_comp, fb_counts, fb_list, parity);
+extern "C" int sai2b_launch_tick_cert(const sai2b::DevParams* d_params, int B, int max_rows, int with_comp, int* fb_counts, int* fb_list,
+									  int parity, hipStream_t stream) {
+	const dim3 grid((B + 63) / 64), block(64);
+	if (max_rows <= 3)
+		hipLaunchKernelGGL(sai2b::tick_cert_kernel<3>, grid, block, 0, stream, d_params, with_comp, fb_counts, fb_list, parity);
+	else
+		hipLaunchKernelGGL(sai2b::tick_cert_kernel<sai2b::cert::MM>, grid, block, 0, stream, d_params, with_comp, fb_counts, fb_list, parity);
 	return (int)hipGetLastError();
 }

@@ -697,7 +697,7 @@ DI bool certify_gram(const real* G, const real* Pc, real abs2, real rel2) {
 		t8 += (i == j) ? v : 2 * v;
 	}
 	const real ub = sqrt(sqrt(sqrt(t8)));
-	bool ok = ub > 1.28 * abs2;	 // lambda_max >= ub / n^(1/8), 7^(1/8) = 1.2754
+	bool ok = ub > 1.30 * abs2;	 // lambda_max >= ub / n^(1/8), 8^(1/8) = 1.2968
 	const real c = rel2 * ub * (1.0 + 1e-9);
 	const real floor_ = 1e-5 * c;
 	real Lm[n * n], d[n];

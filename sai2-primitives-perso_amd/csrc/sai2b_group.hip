@@ -25,7 +25,9 @@ __global__ __launch_bounds__(64) SAI2B_GROUP_OCC void tick_group_kernel(const De
 	if (fb_count) {
 		const int cnt = *(const gint*)fb_count;
 #pragma unroll 1
-		for (int e = blockIdx.x * GPB + gi; e < cnt; e += gridDim.x * GPB)
+		// entry e -> workgroup e % gridDim.x: a short list gives every robot a wavefront of its own (robots of one
+		// wavefront that take different branches run one after the other)
+		for (int e = blockIdx.x + gi * gridDim.x; e < cnt; e += gridDim.x * GPB)
 			grp::tick_robot<G, RANGE>(P, ((const gint*)fb_list)[e], pads[gi], commit_sh, with_comp, do_torque);
 		return;
 	}

@@ -918,25 +918,28 @@ extern "C" int sai2b_reinitialize(sai2b_ctx* ctx) {
 
 // eligibility of the SVD-free path (sai2b_fast.hpp): [full MFT] or [full MFT, full JT] (any batch size: a robot
 // the kernel declines goes to the generic kernel on its own, lanes past the batch just exit)
-// 3: the SVD-free kernel for general hierarchies (sai2b_cert.hpp): any robot size and joint type, any sequence of
-// tasks whose rows can all be independent (at most N of them, a full JointTask only at the bottom)
+// 3 + r: the SVD-free kernel for general hierarchies (sai2b_cert.hpp): any robot size and joint type, any sequence
+// of tasks whose rows can all be independent (at most N of them, a full JointTask only at the bottom); r = most
+// rows a partial task brings (selects the kernel's instantiation)
 static int cert_kind(const sai2b_ctx* ctx) {
 	if (ctx->no_fast_path || ctx->no_cert_path || ctx->T < 1) return 0;
-	int rows = 0, slots = N;  // deferred stores per robot (sai2b_cert.hpp: PEND_SLOTS = 48)
+	int rows = 0, max_rows = 0, slots = N;  // deferred stores per robot (sai2b_cert.hpp: PEND_SLOTS = 36)
 	for (int t = 0; t < ctx->T; t++) {
 		const DevTask& d = ctx->h_params.task[t];
 		if (d.type == SAI2B_MOTION_FORCE_TASK) {
 			// the passivity observer mutates per-robot state inside the law: generic kernel only
 			if (ctx->cfg[t].passivity_enabled && ctx->cfg[t].closed_loop_force) return 0;
 			rows += d.rank;
+			max_rows = std::max(max_rows, d.rank);
 			slots += 12;
 		} else {
 			if (d.full_selection && t != ctx->T - 1) return 0;
 			rows += d.full_selection ? 0 : d.k0;
+			if (!d.full_selection) max_rows = std::max(max_rows, d.k0);
 			slots += d.k0;
 		}
 	}
-	return (rows <= N && slots <= 48) ? 3 : 0;
+	return (rows <= N && slots <= 36) ? 3 + max_rows : 0;
 }
 static int fast_kind(const sai2b_ctx* ctx) {
 	// these two kernels are written for 7 revolute joints (a 6-DOF task leaves a one-dimensional nullspace)

@@ -292,8 +292,8 @@ __global__ __launch_bounds__(64) void reinit_kernel(const DevParams* __restrict_
 
 static void launch_fast(int fast, int baked, dim3 grid, dim3 block, hipStream_t stream, const sai2b::DevParams* d_params,
 						int with_comp, int* fb_counts, int* fb_list, int parity) {
-	if (fast == 3) {  // general hierarchies (sai2b_cert.hip)
-		sai2b_launch_tick_cert(d_params, (int)grid.x * 64, with_comp, fb_counts, fb_list, parity, stream);
+	if (fast >= 3) {  // general hierarchies (sai2b_cert.hip); fast - 3 = most rows of a partial task
+		sai2b_launch_tick_cert(d_params, (int)grid.x * 64, fast - 3, with_comp, fb_counts, fb_list, parity, stream);
 		return;
 	}
 #if SAI2B_N == 7

@@ -10,9 +10,10 @@ extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int de
 // generic tick with a robot spread over `lanes` = 16 or 8 lanes (sai2b_group.hip); fb_count / fb_list as tick_kernel
 extern "C" int sai2b_launch_tick_group(const sai2b::DevParams* d_params, int B, int lanes, int range_only, int commit_sh, int with_comp,
 									   int do_torque, const int* fb_count, const int* fb_list, hipStream_t stream);
-// the SVD-free tick for general hierarchies (sai2b_cert.hip): fills the work list like the fast kernels (fast = 3)
-extern "C" int sai2b_launch_tick_cert(const sai2b::DevParams* d_params, int B, int with_comp, int* fb_counts, int* fb_list, int parity,
-									  hipStream_t stream);
+// the SVD-free tick for general hierarchies (sai2b_cert.hip): fills the work list like the fast kernels.
+// max_rows: most rows of a partial task of the hierarchy (selects the instantiation)
+extern "C" int sai2b_launch_tick_cert(const sai2b::DevParams* d_params, int B, int max_rows, int with_comp, int* fb_counts, int* fb_list,
+									  int parity, hipStream_t stream);
 extern "C" int sai2b_launch_range_pass(const sai2b::DevParams* d_params, int B, int debug, int with_comp, int group, hipStream_t stream);
 // only_task < 0: every task (RobotController::reinitializeTasks); else TemplateTask::reInitializeTask of that one
 extern "C" int sai2b_launch_reinit(const sai2b::DevParams* d_params, int B, int only_task, hipStream_t stream);
