@@ -196,7 +196,7 @@ def main():
                 "workload": {2: f"C2: {B} batched Panda, one 6-DOF MotionForceTask",
                              3: f"C3: {B} batched Panda per GPU, MotionForceTask(6) + nullspace JointTask",
                              4: f"C4: {B} batched Panda, partial MotionForceTask(3) + partial JointTask(2) + full JointTask, "
-                                "singularity handling on (generic kernel, a robot spread over 8 lanes)",
+                                "singularity handling on (SVD-free kernel for general hierarchies + generic kernel over its work list)",
                              5: f"C5: {B} batched Panda per GPU (C3 workload sharded)"}[args.config]
                             + ", library defaults, OTG off (SURVEY.md §8(d))",
                 "robots_per_gpu": B,
@@ -210,7 +210,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic_bytes() if args.config in (3, 5) and B == 65536 else None,
-                "kernel": {2: "sai2b::tick_fast_kernel<1>", 3: "sai2b::tick_fast_kernel<2>", 4: "sai2b::tick_group_kernel<8>",
+                "kernel": {2: "sai2b::tick_fast_kernel<1>", 3: "sai2b::tick_fast_kernel<2>", 4: "sai2b::tick_cert_kernel<3>",
                            5: "sai2b::tick_fast_kernel<2>"}[args.config],
                 "kernel_ms": kernel_ms,
                 "fallback_kernel_ms": fallback_ms,

@@ -45,6 +45,6 @@ extern "C" int sai2b_launch_tick_cert(const sai2b::DevParams* d_params, int B, i
 	if (max_rows <= 3)
 		hipLaunchKernelGGL(sai2b::tick_cert_kernel<3>, grid, block, 0, stream, d_params, with_comp, fb_counts, fb_list, parity);
 	else
-		hipLaunchKernelGGL(sai2b::tick_cert_kernel<sai2b::cert::MM>, grid, block, 0, stream, d_params, with_comp, fb_counts, fb_list, parity);
+		hipLaunchKernelGGL(sai2b::tick_cert_kernel<6>, grid, block, 0, stream, d_params, with_comp, fb_counts, fb_list, parity);
 	return (int)hipGetLastError();
 }

@@ -54,6 +54,44 @@ DI void load_lb(const real* lb, real* LB, real* dB) {
 
 DI real symat(const real* Q, int i, int j) { return i >= j ? Q[i * N + j] : Q[j * N + i]; }  // lower triangle kept
 
+// certify_gram of sai2b_device.hpp with the live set of a triangle: G (lower triangle, row-major n x n storage),
+// lambda_max <= ub := tr(G^8)^(1/8) <= n^(1/8) lambda_max and positive LDL^T pivots of G - rel2 ub I
+template <int n>
+DI real lower(const real* A, int i, int j) { return i >= j ? A[i * n + j] : A[j * n + i]; }
+template <int n>
+DI bool certify_gram_lower(const real* G, real abs2, real rel2) {
+	real G2[n * n];
+	UNROLL for (int i = 0; i < n; i++) UNROLL for (int j = 0; j <= i; j++) {
+		real s = 0;
+		UNROLL for (int l = 0; l < n; l++) s = fma(lower<n>(G, i, l), lower<n>(G, j, l), s);
+		G2[i * n + j] = s;
+	}
+	real t8 = 0;
+	UNROLL for (int i = 0; i < n; i++) UNROLL for (int j = 0; j <= i; j++) {
+		real s = 0;
+		UNROLL for (int l = 0; l < n; l++) s = fma(lower<n>(G2, i, l), lower<n>(G2, j, l), s);
+		t8 = fma(s, (i == j) ? s : 2 * s, t8);
+	}
+	const real ub = sqrt(sqrt(sqrt(t8)));
+	bool ok = ub > 1.30 * abs2;	 // lambda_max >= ub / n^(1/8), 8^(1/8) = 1.2968
+	const real c = rel2 * ub * (1.0 + 1e-9);
+	const real floor_ = 1e-5 * c;
+	real Lm[n * n], d[n];
+	UNROLL for (int j = 0; j < n; j++) {
+		real s = G[j * n + j] - c;
+		UNROLL for (int k = 0; k < j; k++) s = fma(-Lm[j * n + k] * Lm[j * n + k], d[k], s);
+		d[j] = s;
+		ok = ok && (s > floor_);
+		const real inv = 1.0 / s;
+		UNROLL for (int i = j + 1; i < n; i++) {
+			real t = G[i * n + j];
+			UNROLL for (int k = 0; k < j; k++) t = fma(-Lm[i * n + k] * Lm[j * n + k], d[k], t);
+			Lm[i * n + j] = t * inv;
+		}
+	}
+	return ok;
+}
+
 // One level of the cascade in reduced coordinates, M rows exactly (an instantiation per task size: the arrays of
 // a 3-row task are 3 columns wide, nothing is guarded). Jr: the task's rows (Jr[c * N + i]).
 // Task forces: Lambda va + Lambda_mod vf + vd with Lambda_mod by the decoupling type (SingularityHandler.cpp:
@@ -87,12 +125,17 @@ DI bool level(const Fact& f, const real* Jr, bool first, bool last, bool do_cert
 			}
 		}
 		UNROLL for (int i = 0; i < N; i++) Y[c * N + i] = col[i];
+		__builtin_amdgcn_sched_barrier(0);	// one column at a time: interleaving them only inflates the live set
 	}
 	bool ok = true;
 	if (do_cert) {
 		real G[M * M];
-		mm_nt_sym<M, N>(JP, JP, G);
-		ok = certify_gram<M>(G, nullptr, abs2, rel2);
+		UNROLL for (int i = 0; i < M; i++) UNROLL for (int j = 0; j <= i; j++) {
+			real s = 0;
+			UNROLL for (int l = 0; l < N; l++) s = fma(JP[i * N + l], JP[j * N + l], s);
+			G[i * M + j] = s;
+		}
+		ok = certify_gram_lower<M>(G, abs2, rel2);
 	}
 	SAI2B_PHASE();
 	const bool full = decoupling == SAI2B_FULL_DYNAMIC_DECOUPLING;
@@ -105,11 +148,23 @@ DI bool level(const Fact& f, const real* Jr, bool first, bool last, bool do_cert
 	}
 	if (decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES) {
 		// Lambda_mod = (Jp M_BIE^-1 Jp^T)^-1 = (YB^T YB)^-1, YB = LB^-1 Jp^T; torques Jp^T x = LB (YB x)
-		real LB[N * N], dB[N];
-		load_lb(f.lb, LB, dB);
-		UNROLL for (int c = 0; c < M; c++) solve_lower<N>(LB, dB, JP + c * N);
+		// LB comes from LDS a row at a time (each row serves all M columns): it is never whole in registers
+		UNROLL for (int i = 0; i < N; i++) {
+			real row[N];
+			UNROLL for (int k = 0; k < i; k++) row[k] = f.lb[(i * (i + 1) / 2 + k) * 64];
+			const real di = f.lb[(N * (N + 1) / 2 + i) * 64];
+			UNROLL for (int c = 0; c < M; c++) {
+				real t = JP[c * N + i];
+				UNROLL for (int k = 0; k < i; k++) t = fma(-row[k], JP[c * N + k], t);
+				JP[c * N + i] = t * di;
+			}
+		}
 		real AB[M * M], LA[M * M], dA[M], y[M];
-		mm_nt_sym<M, N>(JP, JP, AB);
+		UNROLL for (int i = 0; i < M; i++) UNROLL for (int j = 0; j <= i; j++) {
+			real s = 0;
+			UNROLL for (int l = 0; l < N; l++) s = fma(JP[i * N + l], JP[j * N + l], s);
+			AB[i * M + j] = s;
+		}
 		chol<M>(AB, LA, dA);
 		UNROLL for (int c = 0; c < M; c++) y[c] = vf[c];
 		solve_lower<M>(LA, dA, y);
@@ -122,7 +177,7 @@ DI bool level(const Fact& f, const real* Jr, bool first, bool last, bool do_cert
 		}
 		UNROLL for (int i = 0; i < N; i++) {
 			real s = 0;
-			UNROLL for (int k = 0; k <= i; k++) s = fma(LB[i * N + k], w[k], s);
+			UNROLL for (int k = 0; k <= i; k++) s = fma(f.lb[(i * (i + 1) / 2 + k) * 64], w[k], s);
 			tau[i] += s;
 		}
 	}
@@ -277,7 +332,7 @@ DI void full_joint_task_behind_any(int d, const Fact& f, int decoupling, const r
 
 // JWorldFrame(link, pos) and the pose of the control frame from the joint positions (fk + frame_pose + jacobian of
 // sai2b_device.hpp in one sweep that keeps only the joint axes and origins, not every link frame)
-DI void jacobian_and_pose(const DevModel& md, const DevTask& t, const real* q, real* J, real* x, real* R) {
+DI void jacobian_and_pose(const DevModel& md, const DevTask& t, const real* q, const real* sc, real* J, real* x, real* R) {
 	real Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pp[3] = {0, 0, 0};
 	real z[N][3], o[N][3];
 	UNROLL for (int k = 0; k < 3; k++) x[k] = 0;
@@ -287,10 +342,8 @@ DI void jacobian_and_pose(const DevModel& md, const DevTask& t, const real* q, r
 		UNROLL for (int k = 0; k < 3; k++)
 			pi[k] = fma(Rp[3 * k], md.xyz[i][0], fma(Rp[3 * k + 1], md.xyz[i][1], fma(Rp[3 * k + 2], md.xyz[i][2], pp[k])));
 		mm<3, 3, 3>(Rp, md.E[i], RE);
-		real s, c;
-		sincos_joint(q[i], &s, &c);
+		const real s = sc[2 * i], c = sc[2 * i + 1];
 		const bool pris = md.jtype[i] != 0;
-		if (pris) s = 0, c = 1;
 		UNROLL for (int k = 0; k < 3; k++) {
 			Rp[3 * k + 0] = fma(c, RE[3 * k], s * RE[3 * k + 1]);
 			Rp[3 * k + 1] = fma(c, RE[3 * k + 1], -s * RE[3 * k]);
@@ -315,6 +368,59 @@ DI void jacobian_and_pose(const DevModel& md, const DevTask& t, const real* q, r
 			J[k * N + i] = on ? (pris ? z[i][k] : v[k]) : 0.0;
 			J[(3 + k) * N + i] = (on && !pris) ? z[i][k] : 0.0;
 		}
+	}
+}
+
+// Pose of the control frame and its velocity J dq in one sweep over the joints, without the Jacobian itself
+// (v = omega x x_frame - sum dq_i z_i x o_i + sliding terms): the control law runs on this, and the Jacobian's 42
+// numbers only come to life afterwards (jacobian_and_pose), when the law's own ~100 are gone.
+// sc: sines and cosines of the joints, kept for the second sweep.
+DI void pose_and_velocity(const DevModel& md, const DevTask& t, const real* q, const real* dq, real* x, real* R, real* vw, real* sc) {
+	real Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pp[3] = {0, 0, 0};
+	real om[3] = {0, 0, 0}, a[3] = {0, 0, 0}, vs[3] = {0, 0, 0};
+	UNROLL for (int k = 0; k < 3; k++) x[k] = 0;
+	UNROLL for (int k = 0; k < 9; k++) R[k] = 0;
+	UNROLL for (int i = 0; i < N; i++) {
+		real RE[9], pi[3];
+		UNROLL for (int k = 0; k < 3; k++)
+			pi[k] = fma(Rp[3 * k], md.xyz[i][0], fma(Rp[3 * k + 1], md.xyz[i][1], fma(Rp[3 * k + 2], md.xyz[i][2], pp[k])));
+		mm<3, 3, 3>(Rp, md.E[i], RE);
+		real s, c;
+		sincos_joint(q[i], &s, &c);
+		const bool pris = md.jtype[i] != 0;
+		if (pris) s = 0, c = 1;
+		sc[2 * i] = s, sc[2 * i + 1] = c;
+		UNROLL for (int k = 0; k < 3; k++) {
+			Rp[3 * k + 0] = fma(c, RE[3 * k], s * RE[3 * k + 1]);
+			Rp[3 * k + 1] = fma(c, RE[3 * k + 1], -s * RE[3 * k]);
+			Rp[3 * k + 2] = RE[3 * k + 2];
+			if (pris) pi[k] = fma(q[i], RE[3 * k + 2], pi[k]);
+			pp[k] = pi[k];
+		}
+		if (i <= t.link) {	// batch-uniform
+			const real z[3] = {RE[2], RE[5], RE[8]};
+			real zo[3];
+			cross3(z, pi, zo);
+			UNROLL for (int k = 0; k < 3; k++) {
+				if (pris) {
+					vs[k] = fma(dq[i], z[k], vs[k]);
+				} else {
+					om[k] = fma(dq[i], z[k], om[k]);
+					a[k] = fma(dq[i], zo[k], a[k]);
+				}
+			}
+		}
+		if (t.link == i) {
+			UNROLL for (int k = 0; k < 3; k++)
+				x[k] = fma(Rp[3 * k], t.frame_pos[0], fma(Rp[3 * k + 1], t.frame_pos[1], fma(Rp[3 * k + 2], t.frame_pos[2], pp[k])));
+			mm<3, 3, 3>(Rp, t.frame_rot, R);
+		}
+	}
+	real ox[3];
+	cross3(om, x, ox);
+	UNROLL for (int k = 0; k < 3; k++) {
+		vw[k] = ox[k] - a[k] + vs[k];
+		vw[3 + k] = om[k];
 	}
 }
 
@@ -387,27 +493,28 @@ DI bool tick(const DevParams& P, int B, int b, bool with_comp, real* pend, real*
 			// MotionForceTask::updateTaskModel / computeTorques (MotionForceTask.cpp:247-509) in the fully
 			// non-singular branch of the SingularityHandler (SingularityHandler.cpp:100-141,307-309)
 			ok = ok && (ldi(t.istate, IS_NTYPES, B, b) == 0);
-			real Jw[6 * N], x[3], R[9], Fu[6], Ff[6];
+			real Jw[6 * N], Fu[6], Ff[6];
 			{
-				real q[N];
+				real q[N], sc[2 * N], x[3], R[9];
 				UNROLL for (int i = 0; i < N; i++) q[i] = ld(P.q, i, B, b);
-				jacobian_and_pose(P.model, t, q, Jw, x, R);
-			}
-			{
-				real dq[N], vw0[6], vw[6];
-				UNROLL for (int i = 0; i < N; i++) dq[i] = ld(P.dq, i, B, b);
-				mv<6, N>(Jw, dq, vw0);
-				if (t.full_projection) {
-					UNROLL for (int i = 0; i < 6; i++) vw[i] = vw0[i];
-				} else {
-					mv<6, 6>(t.P, vw0, vw);
+				{
+					real dq[N], vw0[6], vw[6];
+					UNROLL for (int i = 0; i < N; i++) dq[i] = ld(P.dq, i, B, b);
+					pose_and_velocity(P.model, t, q, dq, x, R, vw0, sc);
+					if (t.full_projection) {
+						UNROLL for (int i = 0; i < 6; i++) vw[i] = vw0[i];
+					} else {
+						mv<6, 6>(t.P, vw0, vw);
+					}
+					MftIn in;
+					mft_load(t, B, b, in);
+					mft_law_vw(t, vw, vw + 3, x, R, in, Fu, Ff);
+					// mft_store_integrators, deferred
+					UNROLL for (int k = 0; k < 12; k++) pend[(np + k) * 64] = in.integ[k];
+					np += 12;
 				}
-				MftIn in;
-				mft_load(t, B, b, in);
-				mft_law_vw(t, vw, vw + 3, x, R, in, Fu, Ff);
-				// mft_store_integrators, deferred
-				UNROLL for (int k = 0; k < 12; k++) pend[(np + k) * 64] = in.integ[k];
-				np += 12;
+				SAI2B_PHASE();
+				jacobian_and_pose(P.model, t, q, sc, Jw, x, R);
 			}
 			const int m = t.rank;
 			if (wrows + m > N) ok = false;	// more task rows than joints left: never full rank

@@ -29,4 +29,6 @@ for label, frac in (("regular poses", 0.0), ("1 in 1000 near-singular", 0.001), 
         c.tick(want_output=False)
     c.synchronize()
     dt = (time.perf_counter() - t0) / 30
-    print(f"{label}: {dt * 1e6:.1f} us/step  {B / dt / 1e6:.1f} Mticks/s")
+    k_ms, fb_ms = c.profile_tick(30)
+    print(f"{label}: {dt * 1e6:.1f} us/step  {B / dt / 1e6:.1f} Mticks/s   (first kernel {k_ms * 1e3:.1f} us, work-list pass "
+          f"{fb_ms * 1e3:.1f} us over {c.fallback_count()} robots)")
