@@ -11,6 +11,8 @@ namespace sai2b {
 // fb_counts / fb_list / parity: as tick_fast_kernel (sai2b_kernels.hip). MCAP: most rows a partial task of the
 // hierarchy brings; the instantiation for small tasks (position-only MotionForceTask, a few selected joints) does
 // not carry the register footprint of a 6- or 7-row level.
+// (The robot constants are read from the parameter block: compiling the stock Panda in, as tick_fast_kernel does,
+// measured 9 % SLOWER here — 53.2 vs 49.0 us on the same box — the literals cost registers this kernel does not have.)
 template <int MCAP>
 __global__ __launch_bounds__(64) void tick_cert_kernel(const DevParams* __restrict__ Pp, int with_comp, int* __restrict__ fb_counts,
 													  int* __restrict__ fb_list, int parity) {
@@ -22,7 +24,7 @@ __global__ __launch_bounds__(64) void tick_cert_kernel(const DevParams* __restri
 	if (b >= B) return;
 	real* pend = pend_lds + threadIdx.x;
 	real tau[N];
-	const bool mine = cert::tick<MCAP, cert::DM>(P, B, b, with_comp != 0, pend, tau);
+	const bool mine = cert::tick<MCAP, cert::DM>(P, P.model, B, b, with_comp != 0, pend, tau);
 	const unsigned long long declined = __ballot(!mine);
 	if (declined) {
 		int base = 0;

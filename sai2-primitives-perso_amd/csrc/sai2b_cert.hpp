@@ -332,7 +332,8 @@ DI void full_joint_task_behind_any(int d, const Fact& f, int decoupling, const r
 
 // JWorldFrame(link, pos) and the pose of the control frame from the joint positions (fk + frame_pose + jacobian of
 // sai2b_device.hpp in one sweep that keeps only the joint axes and origins, not every link frame)
-DI void jacobian_and_pose(const DevModel& md, const DevTask& t, const real* q, const real* sc, real* J, real* x, real* R) {
+template <class MD>
+DI void jacobian_and_pose(const MD& md, const DevTask& t, const real* q, const real* sc, real* J, real* x, real* R) {
 	real Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pp[3] = {0, 0, 0};
 	real z[N][3], o[N][3];
 	UNROLL for (int k = 0; k < 3; k++) x[k] = 0;
@@ -375,7 +376,8 @@ DI void jacobian_and_pose(const DevModel& md, const DevTask& t, const real* q, c
 // (v = omega x x_frame - sum dq_i z_i x o_i + sliding terms): the control law runs on this, and the Jacobian's 42
 // numbers only come to life afterwards (jacobian_and_pose), when the law's own ~100 are gone.
 // sc: sines and cosines of the joints, kept for the second sweep.
-DI void pose_and_velocity(const DevModel& md, const DevTask& t, const real* q, const real* dq, real* x, real* R, real* vw, real* sc) {
+template <class MD>
+DI void pose_and_velocity(const MD& md, const DevTask& t, const real* q, const real* dq, real* x, real* R, real* vw, real* sc) {
 	real Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pp[3] = {0, 0, 0};
 	real om[3] = {0, 0, 0}, a[3] = {0, 0, 0}, vs[3] = {0, 0, 0};
 	UNROLL for (int k = 0; k < 3; k++) x[k] = 0;
@@ -442,8 +444,9 @@ DI void mul_llt(const real* L, const real* x, real* y) {
 // The whole tick of one robot. pend: this lane's column of the deferred-store buffer (stride 64 doubles).
 // Returns whether every task was certified (and no MotionForceTask is inside / leaving a singular region): only
 // then may the caller flush the deferred stores and write tau.
-template <int MCAP, int DCAP>
-DI bool tick(const DevParams& P, int B, int b, bool with_comp, real* pend, real* tau) {
+// MD: where the robot constants come from (the parameter block, or the compile-time Panda of sai2b_baked_panda.h)
+template <int MCAP, int DCAP, class MD>
+DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, real* pend, real* tau) {
 	Fact f;
 	bool ok = true;
 	int np = N;	 // deferred-store slots used so far: 0..N-1 hold the gravity torques
@@ -452,12 +455,12 @@ DI bool tick(const DevParams& P, int B, int b, bool with_comp, real* pend, real*
 		real q[N];
 		UNROLL for (int i = 0; i < N; i++) q[i] = ld(P.q, i, B, b);
 		Frames F;
-		fk(P.model, q, F);
+		fk(md, q, F);
 		real M[N * N];
-		mass_matrix(P.model, F, M);
+		mass_matrix(md, F, M);
 		if (P.gravity_comp) {
 			real g[N];
-			gravity_vector(P.model, F, g);
+			gravity_vector(md, F, g);
 			UNROLL for (int i = 0; i < N; i++) pend[i * 64] = g[i];
 		} else {
 			UNROLL for (int i = 0; i < N; i++) pend[i * 64] = 0.0;
@@ -500,7 +503,7 @@ DI bool tick(const DevParams& P, int B, int b, bool with_comp, real* pend, real*
 				{
 					real dq[N], vw0[6], vw[6];
 					UNROLL for (int i = 0; i < N; i++) dq[i] = ld(P.dq, i, B, b);
-					pose_and_velocity(P.model, t, q, dq, x, R, vw0, sc);
+					pose_and_velocity(md, t, q, dq, x, R, vw0, sc);
 					if (t.full_projection) {
 						UNROLL for (int i = 0; i < 6; i++) vw[i] = vw0[i];
 					} else {
@@ -514,7 +517,7 @@ DI bool tick(const DevParams& P, int B, int b, bool with_comp, real* pend, real*
 					np += 12;
 				}
 				SAI2B_PHASE();
-				jacobian_and_pose(P.model, t, q, sc, Jw, x, R);
+				jacobian_and_pose(md, t, q, sc, Jw, x, R);
 			}
 			const int m = t.rank;
 			if (wrows + m > N) ok = false;	// more task rows than joints left: never full rank

@@ -939,7 +939,8 @@ static int cert_kind(const sai2b_ctx* ctx) {
 			slots += d.k0;
 		}
 	}
-	return (rows <= N && slots <= 36) ? 3 + max_rows : 0;
+	// (the kernel is instantiated for partial tasks of up to 6 rows)
+	return (rows <= N && slots <= 36 && max_rows <= 6) ? 3 + max_rows : 0;
 }
 static int fast_kind(const sai2b_ctx* ctx) {
 	// these two kernels are written for 7 revolute joints (a 6-DOF task leaves a one-dimensional nullspace)
