@@ -23,10 +23,18 @@
 #else
 #define SAI2B_DET_FN static inline
 #endif
+/* clang (hipcc): no contraction inside these functions whatever the translation unit's setting; gcc builds (the
+ * oracle) pass -ffp-contract=off */
+#if defined(__clang__)
+#define SAI2B_DET_PRAGMA _Pragma("clang fp contract(off)")
+#else
+#define SAI2B_DET_PRAGMA
+#endif
 
 /* sin and cos of x (|x| < ~1e5). Argument reduction by pi/2 in three exactly representable pieces (fdlibm's
  * pio2_1 .. pio2_3: k * piece is exact for |k| < 2^20), then the minimax kernels on [-pi/4, pi/4]. */
 SAI2B_DET_FN void sai2b_det_sincos(double x, double* sn, double* cs) {
+	SAI2B_DET_PRAGMA
 	const double invpio2 = 6.36619772367581382433e-01;
 	const double pio2_1 = 1.57079632673412561417e+00, pio2_2 = 6.07710050630396597660e-11, pio2_3 = 2.02226624871116645580e-21;
 	const double pio2_3t = 8.47842766036889956997e-32;
@@ -52,6 +60,7 @@ SAI2B_DET_FN void sai2b_det_sincos(double x, double* sn, double* cs) {
 
 /* atan(t) for t >= 0: fdlibm's argument reduction at 7/16, 11/16, 19/16, 39/16 and its odd / even polynomial */
 SAI2B_DET_FN double sai2b_det_atan_pos(double t) {
+	SAI2B_DET_PRAGMA
 	const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
 	double x = t, hi = 0.0, lo = 0.0;
 	int reduced = 1;
@@ -82,6 +91,7 @@ SAI2B_DET_FN double sai2b_det_atan_pos(double t) {
 
 /* atan2(y, x) for y >= 0 and x >= 0 (the only quadrant the wrapper needs: atan2(|q_xyz|, |q_w|)) */
 SAI2B_DET_FN double sai2b_det_atan2_pos(double y, double x) {
+	SAI2B_DET_PRAGMA
 	if (x == 0.0) return (y == 0.0) ? 0.0 : 1.57079632679489655800e+00 + 6.12323399573676603587e-17;
 	return sai2b_det_atan_pos(y / x);
 }

@@ -8,6 +8,7 @@
  */
 #include "sai2_oracle.h"
 #include "otg_oracle.h"
+#include "../include/sai2b_detfk.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -749,6 +750,14 @@ static void frame_pose(const sai2b_task_config* t, const double Rl[N7][9], const
 	mm(3, 3, 3, Rl[t->link], t->frame_rot, R);
 }
 
+/* The pose a MotionForceTask's goals and internal OTG START from (re-initialisation, OTG enable, force / motion
+ * space re-parametrisation): the bit-reproducible forward kinematics shared with the product's initialisation
+ * kernels (include/sai2b_detfk.h), so that both sides' generators see identical bits and take the same planner
+ * branches. Everything on the torque path uses fk() / frame_pose() above, this oracle's own. */
+static void det_pose(const oracle_ctx* c, const sai2b_task_config* t, const double* q, double* x, double* R) {
+	sai2b_det_frame_pose(&c->E[0][0], &c->model.joint_xyz[0][0], c->model.joint_type, q, t->link, t->frame_pos, t->frame_rot, x, R);
+}
+
 /* Sai2Model::operationalSpaceMatrices(J) as DEFINED in SURVEY App. D:
  * Lambda = (J M^-1 J^T)^-1, Jbar = M^-1 J^T Lambda, N = I - Jbar J */
 static void opspace(const robot_t* r, int m, const double* J, double* L, double* Jbar, double* N) {
@@ -894,9 +903,9 @@ static void jt_compensation(const sai2b_task_config* t, const robot_t* r, const 
 }
 
 /* ---- MotionForceTask + SingularityHandler ---- */
-static void mft_reinit(const sai2b_task_config* t, const robot_t* r, mft_t* s, otg_cartesian* o) {
+static void mft_reinit(const oracle_ctx* c, const sai2b_task_config* t, const robot_t* r, mft_t* s, otg_cartesian* o) {
 	/* MotionForceTask.cpp:204-245; SingularityHandler.cpp:53-63 */
-	frame_pose(t, r->Rl, r->pl, s->g_pos, s->g_rot);
+	det_pose(c, t, r->q, s->g_pos, s->g_rot);
 	for (int i = 0; i < 3; i++) {
 		s->g_v[i] = s->g_w[i] = s->g_a[i] = s->g_al[i] = s->g_f[i] = s->g_m[i] = 0;
 		s->sens_f[i] = s->sens_m[i] = 0;
@@ -916,11 +925,11 @@ static void mft_otg_enable(const sai2b_task_config* t, const mft_t* s, otg_carte
 							 t->otg_max_angular_velocity, t->otg_max_angular_acceleration);
 }
 /* MotionForceTask::initialSetup, OTG part + reInitializeTask (MotionForceTask.cpp:100-103,170-201) */
-static void mft_construct(const sai2b_task_config* t, const robot_t* r, mft_t* s, otg_cartesian* o) {
-	frame_pose(t, r->Rl, r->pl, s->cur_pos, s->cur_rot);
+static void mft_construct(const oracle_ctx* c, const sai2b_task_config* t, const robot_t* r, mft_t* s, otg_cartesian* o) {
+	det_pose(c, t, r->q, s->cur_pos, s->cur_rot);
 	otg_cartesian_init(o, s->cur_pos, s->cur_rot, t->loop_timestep);
 	if (t->use_internal_otg) mft_otg_enable(t, s, o, 0);
-	mft_reinit(t, r, s, o);
+	mft_reinit(c, t, r, s, o);
 }
 static void popc_init(mft_t* s) { /* POPCExplicitForceControl.cpp:10-22 */
 	s->popc_po = s->popc_ecorr = s->popc_vsum = 0;
@@ -1242,8 +1251,7 @@ static void mft_torques(const oracle_ctx* c, const sai2b_task_config* t, const r
 	frame_pose(t, r->Rl, r->pl, x, R);
 	mm(3, N7, 1, s->J, r->dq, v);
 	mm(3, N7, 1, s->J + J3, r->dq, w);
-	memcpy(s->cur_pos, x, sizeof(s->cur_pos));
-	memcpy(s->cur_rot, R, sizeof(s->cur_rot));
+	det_pose(c, t, r->q, s->cur_pos, s->cur_rot); /* the cached pose later (re)initialisations start from */
 	if (t->pos_range + t->ori_range == 0) return;
 	double sf[9], sp[9], sm[9], so[9];
 	sigma_pair(t->partial_projection, 0, t->force_space_dimension, t->force_axis, R,
@@ -1449,7 +1457,7 @@ oracle_ctx* oracle_create(const sai2b_robot_model* model, const sai2b_task_confi
 				eye(N7, c->jt[i][b].N_prec);
 				c->jt[i][b].k = 0;
 			} else {
-				mft_construct(&c->cfg[i], &c->robots[b], &c->mft[i][b], &c->cotg[i][b]);
+				mft_construct(c, &c->cfg[i], &c->robots[b], &c->mft[i][b], &c->cotg[i][b]);
 				sh_init(c, &c->mft[i][b]);
 				popc_init(&c->mft[i][b]);
 				eye(N7, c->mft[i][b].N_prec);
@@ -1592,7 +1600,7 @@ int oracle_reinitialize(oracle_ctx* c) {
 			if (c->jt[i])
 				jt_reinit(&c->cfg[i], &c->robots[b], &c->jt[i][b], &c->jotg[i][b]);
 			else {
-				mft_reinit(&c->cfg[i], &c->robots[b], &c->mft[i][b], &c->cotg[i][b]);
+				mft_reinit(c, &c->cfg[i], &c->robots[b], &c->mft[i][b], &c->cotg[i][b]);
 				sh_init(c, &c->mft[i][b]);
 			}
 		}
@@ -1725,7 +1733,7 @@ int oracle_task_reinitialize(oracle_ctx* c, int task) {
 		if (c->jt[task])
 			jt_reinit(&c->cfg[task], &c->robots[b], &c->jt[task][b], &c->jotg[task][b]);
 		else {
-			mft_reinit(&c->cfg[task], &c->robots[b], &c->mft[task][b], &c->cotg[task][b]);
+			mft_reinit(c, &c->cfg[task], &c->robots[b], &c->mft[task][b], &c->cotg[task][b]);
 			sh_init(c, &c->mft[task][b]);
 		}
 	}

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "sai2b_params.h"
+#include "../../include/sai2b_detfk.h"
 
 namespace sai2b {
 
@@ -249,6 +250,12 @@ DI void frame_pose(const DevTask& t, const Frames& F, real* x, real* R) {
 	UNROLL for (int k = 0; k < 3; k++)
 		x[k] = fma(Rl[3 * k], t.frame_pos[0], fma(Rl[3 * k + 1], t.frame_pos[1], fma(Rl[3 * k + 2], t.frame_pos[2], pl[k])));
 	mm<3, 3, 3>(Rl, t.frame_rot, R);
+}
+// The pose goals and internal generators START from (reInitializeTask, enableInternalOtg*, re-parametrisation of
+// the force / motion spaces): the bit-reproducible restatement shared with the test oracle (include/sai2b_detfk.h),
+// so that both sides' generators see identical bits. The torque path keeps fk() / frame_pose() above.
+DI void det_frame_pose(const DevModel& md, const DevTask& t, const real* q, real* x, real* R) {
+	sai2b_det_frame_pose(&md.E[0][0], &md.xyz[0][0], md.jtype, q, t.link, t.frame_pos, t.frame_rot, x, R);
 }
 // Sai2Model::JWorldFrame(link, pos): 6 x n, linear rows first; a prismatic joint's column is (z, 0)
 template <class MD>

@@ -254,15 +254,13 @@ __global__ __launch_bounds__(64) void reinit_kernel(const DevParams* __restrict_
 	if (b >= B) return;
 	real q[N];
 	UNROLL for (int i = 0; i < N; i++) q[i] = ld(P.q, i, B, b);
-	Frames F;
-	fk(P.model, q, F);
 #pragma unroll 1
 	for (int t = 0; t < P.n_tasks; t++) {
 		const DevTask& tk = P.task[t];
 		if (only_task >= 0 && t != only_task) continue;	 // TemplateTask::reInitializeTask of one task
 		if (tk.type == SAI2B_MOTION_FORCE_TASK) {
 			real x[3], R[9];
-			frame_pose(tk, F, x, R);
+			det_frame_pose(P.model, tk, q, x, R);
 			UNROLL for (int k = 0; k < 3; k++) st(tk.goals, k, B, b, x[k]);
 			UNROLL for (int k = 0; k < 9; k++) st(tk.goals, 3 + k, B, b, R[k]);
 			for (int k = 12; k < MFT_GOAL_ROWS; k++) st(tk.goals, k, B, b, 0.0);

@@ -475,10 +475,8 @@ __global__ __launch_bounds__(64) void otg_reinit_kernel(const DevParams* __restr
 	const int b = blockIdx.x * 64 + threadIdx.x;
 	if (b >= B) return;
 	real q[N];
-	Frames F;
 	if (mode == 1) {
 		UNROLL for (int i = 0; i < N; i++) q[i] = ld(q_pose, i, B, b);
-		fk(P.model, q, F);
 	}
 #pragma unroll 1
 	for (int t = 0; t < P.n_tasks; t++) {
@@ -513,7 +511,7 @@ __global__ __launch_bounds__(64) void otg_reinit_kernel(const DevParams* __restr
 		} else {
 			real x[3], R[9];
 			if (mode == 1) {
-				frame_pose(tk, F, x, R);
+				det_frame_pose(P.model, tk, q, x, R);
 			} else {
 				UNROLL for (int k = 0; k < 3; k++) x[k] = ld(tk.goals, k, B, b);
 				UNROLL for (int k = 0; k < 9; k++) R[k] = ld(tk.goals, 3 + k, B, b);
@@ -546,10 +544,8 @@ __global__ __launch_bounds__(64) void mft_reparam_kernel(const DevParams* __rest
 	const DevTask& tk = P.task[task];
 	if (flags & 3) {
 		real q[N], x[3], R[9];
-		Frames F;
 		UNROLL for (int i = 0; i < N; i++) q[i] = ld(q_pose, i, B, b);
-		fk(P.model, q, F);
-		frame_pose(tk, F, x, R);
+		det_frame_pose(P.model, tk, q, x, R);
 		real* S = tk.otg_state;
 		Gen g;
 		load_head(S, 6, true, B, b, g);
