@@ -42,6 +42,15 @@ struct sai2b_ctx {
 	int* fb_counts = nullptr;	// [2] robots the SVD-free kernel handed to the generic one (alternating by fb_parity)
 	int* fb_list = nullptr;		// [B] their indices
 	int fb_parity = 0;			// counter set of the last SVD-free launch
+	// How many robots the SVD-free kernel for general hierarchies keeps is a property of the workload (a 6-DOF task
+	// behind a partial JointTask is inside a blending region most of the time): every 8th such tick its count of
+	// declined robots comes back to the host (pinned word, never waited for); above 40 % of the batch the next 64
+	// ticks run the generic kernel alone, then the SVD-free kernel is tried again. Results are the same either way.
+	int* fb_seen = nullptr;		// pinned host word
+	hipEvent_t fb_seen_ev = nullptr;
+	bool fb_seen_pending = false;
+	int cert_probe = 0, cert_backoff = 0;
+	bool last_tick_generic_only = false;
 	// The tasks' _current_position / _current_orientation are those of the last torque computation (or
 	// re-initialisation), and enabling an OTG starts its generator there (JointTask.cpp:374-376). While
 	// the state buffer still holds that state nothing is kept; the first write to it afterwards
@@ -634,6 +643,8 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	if ((rc = dev_alloc(ctx, &ctx->q_pose, (size_t)N * Bs))) return rc;
 	if ((rc = dev_alloc(ctx, &ctx->fb_counts, 2))) return rc;
 	if ((rc = dev_alloc(ctx, &ctx->fb_list, Bs))) return rc;
+	HIP_TRY(ctx, hipHostMalloc((void**)&ctx->fb_seen, sizeof(int), hipHostMallocDefault));
+	HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fb_seen_ev, hipEventDisableTiming));
 	if ((rc = dev_alloc(ctx, &ctx->otg_counts, 2 * SAI2B_MAX_TASKS))) return rc;
 	if ((rc = dev_alloc(ctx, &ctx->otg_list, SAI2B_MAX_TASKS * Bs))) return rc;
 	for (int t = 0; t < n_tasks; t++) {
@@ -703,6 +714,8 @@ extern "C" void sai2b_destroy(sai2b_ctx* ctx) {
 	for (void* p : ctx->allocs) (void)hipFree(p);
 	if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
 	if (ctx->ev_out) (void)hipEventDestroy(ctx->ev_out);
+	if (ctx->fb_seen_ev) (void)hipEventDestroy(ctx->fb_seen_ev);
+	if (ctx->fb_seen) (void)hipHostFree(ctx->fb_seen);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -1020,11 +1033,29 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 		ctx->otg_parity ^= 1;
 		ctx->launches += 2;
 	}
-	const bool fast_launch = fast != 0 && !ctx->introspection && do_torque && commit_sh;
+	int fast_now = fast;
+	const bool fast_wanted = fast != 0 && !ctx->introspection && do_torque && commit_sh;
+	if (fast_wanted && fast >= 3) {	 // the kernel for general hierarchies: only while it keeps most of the batch
+		if (ctx->fb_seen_pending && hipEventQuery(ctx->fb_seen_ev) == hipSuccess) {
+			ctx->fb_seen_pending = false;
+			if ((long long)*ctx->fb_seen * 5 > (long long)ctx->B * 2) ctx->cert_backoff = 64;
+		}
+		if (ctx->cert_backoff > 0) {
+			ctx->cert_backoff--;
+			fast_now = 0;
+		}
+	}
+	const bool fast_launch = fast_wanted && fast_now != 0;
+	ctx->last_tick_generic_only = do_torque && commit_sh && !fast_launch && !ctx->introspection;
 	if (fast_launch) ctx->fb_parity ^= 1;
-	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, ctx->baked_model ? 1 : 0, commit_sh, with_comp, do_torque, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, !fast_launch), ctx->stream))
+	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast_now, ctx->baked_model ? 1 : 0, commit_sh, with_comp, do_torque, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, !fast_launch), ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
 	ctx->launches++;
+	if (fast_launch && fast >= 3 && !ctx->fb_seen_pending && (ctx->cert_probe++ & 7) == 0) {
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->fb_seen, ctx->fb_counts + ctx->fb_parity, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipEventRecord(ctx->fb_seen_ev, ctx->stream));
+		ctx->fb_seen_pending = true;
+	}
 	if (do_torque) ctx->q_is_pose = true;  // computeTorques caches the tasks' current pose
 	return SAI2B_OK;
 }
@@ -1519,6 +1550,10 @@ extern "C" int sai2b_profile_tick(sai2b_ctx* ctx, int steps, double* first_ms, d
 extern "C" int sai2b_get_fallback_count(sai2b_ctx* ctx, int* robots) {
 	if (!ctx || !robots) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_get_fallback_count: bad arguments");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (ctx->last_tick_generic_only) {	// no SVD-free kernel ran in front: every robot took the generic kernel
+		*robots = ctx->B;
+		return SAI2B_OK;
+	}
 	HIP_TRY(ctx, hipMemcpyAsync(robots, ctx->fb_counts + ctx->fb_parity, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return SAI2B_OK;
