@@ -41,6 +41,21 @@ __global__ __launch_bounds__(64) void tick_cert_kernel(const DevParams* __restri
 
 }  // namespace sai2b
 
+#ifdef SAI2B_CERT_STAMP
+// diagnostic build only (scripts/micro/cert_stamps.py)
+extern "C" void sai2b_debug_reset_cstamps() {
+	int zero = 0;
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(sai2b::cert::g_cstamp_n), &zero, sizeof(int));
+}
+extern "C" int sai2b_debug_read_cstamps(unsigned long long* out, int cap) {
+	int n = 0;
+	(void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(sai2b::cert::g_cstamp_n), sizeof(int));
+	if (2 * n > cap) n = cap / 2;
+	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(sai2b::cert::g_cstamps), sizeof(unsigned long long) * 2 * n);
+	return n;
+}
+#endif
+
 extern "C" int sai2b_launch_tick_cert(const sai2b::DevParams* d_params, int B, int max_rows, int with_comp, int* fb_counts, int* fb_list,
 									  int parity, hipStream_t stream) {
 	const dim3 grid((B + 63) / 64), block(64);

@@ -30,6 +30,28 @@
 namespace sai2b {
 namespace cert {
 
+// -DSAI2B_CERT_STAMP (diagnostic build, scripts/micro/cert_stamps.py): lane 0 of workgroup 0 records (mark, cycle
+// counter) at every CSTAMP into g_cstamps: where one wavefront's cycles go
+#ifdef SAI2B_CERT_STAMP
+__device__ unsigned long long g_cstamps[1024];
+__device__ int g_cstamp_n;
+#define CSTAMP(id)                                                        \
+	do {                                                                  \
+		__builtin_amdgcn_sched_barrier(0);                                \
+		if (blockIdx.x == 0 && threadIdx.x == 0) {                        \
+			const int k_ = g_cstamp_n;                                    \
+			if (k_ < 500) {                                               \
+				g_cstamps[2 * k_] = (unsigned long long)(id);             \
+				g_cstamps[2 * k_ + 1] = __builtin_readcyclecounter();     \
+				g_cstamp_n = k_ + 1;                                      \
+			}                                                             \
+		}                                                                 \
+		__builtin_amdgcn_sched_barrier(0);                                \
+	} while (0)
+#else
+#define CSTAMP(id) do { } while (0)
+#endif
+
 constexpr int MM = N > 6 ? N : 6;  // most rows one task brings (MotionForceTask: 6, JointTask: N)
 constexpr int DM = N - 1;		   // largest nullspace a full JointTask behind another task can see
 constexpr int PEND_SLOTS = 36;	   // deferred stores per robot: gravity N, MotionForceTask 12, JointTask k0
@@ -127,6 +149,7 @@ DI bool level(const Fact& f, const real* Jr, bool first, bool last, bool do_cert
 		UNROLL for (int i = 0; i < N; i++) Y[c * N + i] = col[i];
 		__builtin_amdgcn_sched_barrier(0);	// one column at a time: interleaving them only inflates the live set
 	}
+	CSTAMP(20);
 	bool ok = true;
 	if (do_cert) {
 		real G[M * M];
@@ -138,6 +161,7 @@ DI bool level(const Fact& f, const real* Jr, bool first, bool last, bool do_cert
 		ok = certify_gram_lower<M>(G, abs2, rel2);
 	}
 	SAI2B_PHASE();
+	CSTAMP(21);
 	const bool full = decoupling == SAI2B_FULL_DYNAMIC_DECOUPLING;
 	{  // direct terms: Jp^T (vd (+ vf with IMPEDANCE: Lambda_mod = projector onto the range))
 		const bool imp = decoupling == SAI2B_IMPEDANCE;
@@ -182,6 +206,7 @@ DI bool level(const Fact& f, const real* Jr, bool first, bool last, bool do_cert
 		}
 	}
 	SAI2B_PHASE();
+	CSTAMP(22);
 	// Y = Z R by modified Gram-Schmidt (Z overwrites Y); R upper triangular, rinv its reciprocal diagonal
 	real R[M * M], rinv[M];
 	UNROLL for (int j = 0; j < M; j++) {
@@ -215,10 +240,12 @@ DI bool level(const Fact& f, const real* Jr, bool first, bool last, bool do_cert
 			tau[i] += s;
 		}
 	}
+	CSTAMP(23);
 	if (!last) {
 		UNROLL for (int c = 0; c < M; c++)
 			UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) Q[i * N + j] = fma(-Y[c * N + i], Y[c * N + j], Q[i * N + j]);
 	}
+	CSTAMP(24);
 	return ok;
 }
 // run-time row count (the same for every robot) -> the instantiation
@@ -447,6 +474,7 @@ DI void mul_llt(const real* L, const real* x, real* y) {
 // MD: where the robot constants come from (the parameter block, or the compile-time Panda of sai2b_baked_panda.h)
 template <int MCAP, int DCAP, class MD>
 DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, real* pend, real* tau) {
+	CSTAMP(0);
 	Fact f;
 	bool ok = true;
 	int np = N;	 // deferred-store slots used so far: 0..N-1 hold the gravity torques
@@ -455,9 +483,12 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 		real q[N];
 		UNROLL for (int i = 0; i < N; i++) q[i] = ld(P.q, i, B, b);
 		Frames F;
+		CSTAMP(1);
 		fk(md, q, F);
+		CSTAMP(2);
 		real M[N * N];
 		mass_matrix(md, F, M);
+		CSTAMP(3);
 		if (P.gravity_comp) {
 			real g[N];
 			gravity_vector(md, F, g);
@@ -467,14 +498,9 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 		}
 		SAI2B_PHASE();
 		chol<N>(M, f.L, f.dL);
-		// bounded inertia estimate, shared by the tasks that ask for it (host checks the thresholds agree)
-		bool any_bie = false;
-		real thr = 0;
-		for (int t = 0; t < P.n_tasks; t++)
-			if (P.task[t].decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES) {
-				any_bie = true;
-				thr = P.task[t].bie_threshold;
-			}
+		// bounded inertia estimate, shared by the tasks that ask for it (host: one threshold, upload_params)
+		const bool any_bie = P.any_bie != 0;
+		const real thr = P.bie_thr;
 		if (any_bie) {
 			real LB[N * N], dB[N];
 			UNROLL for (int i = 0; i < N; i++) M[i * N + i] = fmax(M[i * N + i], thr);
@@ -484,6 +510,7 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 		f.lb = pend + PEND_SLOTS * 64;
 	}
 	SAI2B_PHASE();
+	CSTAMP(4);
 	real Q[N * N];
 	UNROLL for (int i = 0; i < N * N; i++) Q[i] = (i % (N + 1) == 0) ? 1.0 : 0.0;
 	UNROLL for (int i = 0; i < N; i++) tau[i] = 0;
@@ -495,6 +522,7 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 		if (t.type == SAI2B_MOTION_FORCE_TASK) {
 			// MotionForceTask::updateTaskModel / computeTorques (MotionForceTask.cpp:247-509) in the fully
 			// non-singular branch of the SingularityHandler (SingularityHandler.cpp:100-141,307-309)
+			CSTAMP(10);
 			ok = ok && (ldi(t.istate, IS_NTYPES, B, b) == 0);
 			real Jw[6 * N], Fu[6], Ff[6];
 			{
@@ -503,21 +531,25 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 				{
 					real dq[N], vw0[6], vw[6];
 					UNROLL for (int i = 0; i < N; i++) dq[i] = ld(P.dq, i, B, b);
+					MftIn in;
+					mft_load(t, B, b, in);	// issued ahead of the sweep: it arrives while the kinematics run
+					CSTAMP(11);
 					pose_and_velocity(md, t, q, dq, x, R, vw0, sc);
+					CSTAMP(12);
 					if (t.full_projection) {
 						UNROLL for (int i = 0; i < 6; i++) vw[i] = vw0[i];
 					} else {
 						mv<6, 6>(t.P, vw0, vw);
 					}
-					MftIn in;
-					mft_load(t, B, b, in);
 					mft_law_vw(t, vw, vw + 3, x, R, in, Fu, Ff);
 					// mft_store_integrators, deferred
 					UNROLL for (int k = 0; k < 12; k++) pend[(np + k) * 64] = in.integ[k];
 					np += 12;
 				}
 				SAI2B_PHASE();
+				CSTAMP(13);
 				jacobian_and_pose(md, t, q, sc, Jw, x, R);
+				CSTAMP(14);
 			}
 			const int m = t.rank;
 			if (wrows + m > N) ok = false;	// more task rows than joints left: never full rank
@@ -537,15 +569,38 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 			wrows += m;
 		} else {
 			// JointTask::updateTaskModel / computeTorques (JointTask.cpp:218-356)
+			CSTAMP(30);
 			const int k0 = t.k0;
 			real va[N], vf[N];
 			{
+				// goals and integrators first, in one burst (rows clamped into the task's own: the loads must not sit
+				// behind the per-coordinate branches), then the state; they arrive behind the compensation solves
+				real gq[N], gdq[N], gddq[N], integ0[N];
+				UNROLL for (int i = 0; i < N; i++) {
+					const int r = i < k0 ? i : k0 - 1;
+					gq[i] = ld(t.law_goals, r, B, b);
+					gdq[i] = ld(t.law_goals, k0 + r, B, b);
+					gddq[i] = ld(t.law_goals, 2 * k0 + r, B, b);
+					integ0[i] = ld(t.state, r, B, b);
+				}
 				real cur[N], vel[N], comp[N];
 				{
 					real q[N], dq[N];
 					UNROLL for (int i = 0; i < N; i++) {
 						q[i] = ld(P.q, i, B, b);
 						dq[i] = ld(P.dq, i, B, b);
+					}
+					UNROLL for (int i = 0; i < N; i++) comp[i] = 0;
+					if (with_comp && !first) {	// JointTask.cpp:285-292: S M^-1 tau_prec
+						real u[N];
+						UNROLL for (int i = 0; i < N; i++) u[i] = tau[i];
+						solve_lower<N>(f.L, f.dL, u);
+						solve_lower_t<N>(f.L, f.dL, u);
+						if (t.full_selection) {
+							UNROLL for (int i = 0; i < N; i++) comp[i] = u[i];
+						} else {
+							mv<N, N>(t.S, u, comp);
+						}
 					}
 					if (t.full_selection) {
 						UNROLL for (int i = 0; i < N; i++) cur[i] = q[i], vel[i] = dq[i];
@@ -554,24 +609,11 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 						mv<N, N>(t.S, dq, vel);
 					}
 				}
-				UNROLL for (int i = 0; i < N; i++) comp[i] = 0;
-				if (with_comp && !first) {	// JointTask.cpp:285-292: S M^-1 tau_prec
-					real u[N];
-					UNROLL for (int i = 0; i < N; i++) u[i] = tau[i];
-					solve_lower<N>(f.L, f.dL, u);
-					solve_lower_t<N>(f.L, f.dL, u);
-					if (t.full_selection) {
-						UNROLL for (int i = 0; i < N; i++) comp[i] = u[i];
-					} else {
-						mv<N, N>(t.S, u, comp);
-					}
-				}
 				UNROLL for (int i = 0; i < N; i++) {
 					va[i] = vf[i] = 0;
 					if (i < k0) {  // PD(+I) law of task coordinate i (JointTask.cpp:299-345)
-						const real* G = t.law_goals;
-						const real qd = ld(G, i, B, b), dqd = ld(G, k0 + i, B, b), ddq_d = ld(G, 2 * k0 + i, B, b);
-						const real integ = fma(cur[i] - qd, t.dt, ld(t.state, i, B, b));
+						const real qd = gq[i], dqd = gdq[i], ddq_d = gddq[i];
+						const real integ = fma(cur[i] - qd, t.dt, integ0[i]);
 						pend[(np + i) * 64] = integ;
 						real fi;
 						if (t.use_vsat) {
@@ -588,6 +630,7 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 				}
 				np += k0;
 			}
+			CSTAMP(31);
 			if (t.full_selection) {
 				if (first) {
 					// Jp = I: M_partial = M, and with the bounded estimate M_BIE (JointTask.cpp:247-265)
@@ -622,6 +665,7 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 			}
 		}
 		if (wrows > N) wrows = N;
+		CSTAMP(40);
 	}
 	return ok;
 }

@@ -594,6 +594,12 @@ static int popc_reinit(sai2b_ctx* ctx, int task) {
 
 static int upload_params(sai2b_ctx* ctx) {
 	if (!ctx->params_dirty) return SAI2B_OK;
+	ctx->h_params.any_bie = 0, ctx->h_params.bie_thr = 0;
+	for (int t = 0; t < ctx->h_params.n_tasks; t++)
+		if (ctx->h_params.task[t].decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES) {
+			ctx->h_params.any_bie = 1;
+			ctx->h_params.bie_thr = ctx->h_params.task[t].bie_threshold;
+		}
 	// stream-ordered so that kernels already enqueued keep the parameters they were launched with
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_params, &ctx->h_params, sizeof(DevParams), hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // h_params may be edited again right after

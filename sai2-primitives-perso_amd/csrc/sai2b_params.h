@@ -128,11 +128,12 @@ struct DevParams {
 	int B;
 	int n_tasks;
 	int gravity_comp;
-	int pad_;
+	int any_bie;	  // some task uses BOUNDED_INERTIA_ESTIMATES (its shared threshold: bie_thr); set by upload_params
 	const double* q;  // [7][B]
 	const double* dq; // [7][B]
 	double* tau;	  // [7][B]
 	double* dbg_M;	  // [49][B] or NULL
+	double bie_thr;
 	DevModel model;
 	DevTask task[SAI2B_MAX_TASKS];
 };
