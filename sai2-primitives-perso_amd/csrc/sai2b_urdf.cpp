@@ -220,7 +220,15 @@ void axis_frame(const double* a, double* A) {
 }
 // rpy with rot_from_rpy(rpy) == R (R = Rz(y) Ry(p) Rx(r))
 void rpy_from_rot(const double* R, double* rpy) {
-	rpy[1] = std::atan2(-R[6], std::sqrt(R[0] * R[0] + R[3] * R[3]));
+	const double cp = std::sqrt(R[0] * R[0] + R[3] * R[3]);
+	rpy[1] = std::atan2(-R[6], cp);
+	if (cp < 1e-9) {
+		// pitch = +-90 degrees (an x axis folded into z, or two folded axes in a row): roll and yaw turn about the
+		// same line and only their difference / sum is defined — all of it goes to the roll
+		rpy[2] = 0.0;
+		rpy[0] = std::atan2(R[6] < 0 ? R[1] : -R[1], R[4]);
+		return;
+	}
 	rpy[2] = std::atan2(R[3], R[0]);
 	rpy[0] = std::atan2(R[7], R[8]);
 }

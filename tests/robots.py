@@ -3,7 +3,10 @@ writer of ours — the GPU box has no /root/reference. tests/test_urdf.py checks
 that these load into the same model as the reference's own files:
   sliding_base : examples/06-partial_joint_task/panda_arm_sliding_base.urdf — the Panda (the library's own constants)
                  on a prismatic joint along y (effort 150, travel -1..1) under a 4 kg base link
-  planar_4r    : examples/11-planar_robot_controller/rrrrbot.urdf — four 0.5 m links, 1 kg each, joints about z"""
+  planar_4r    : examples/11-planar_robot_controller/rrrrbot.urdf — four 0.5 m links, 1 kg each, joints about z
+  six_r        : a 6R arm of PUMA-like geometry (wrist links heavier than a PUMA's: a closed loop on 1e-5 kg m^2 inertias amplifies rounding by the period) (the robot of examples/01-joint_control; its URDF lives in sai2-model's
+                 resources, outside the reference tree: geometry and inertias here are ours), joint axes about z, y, y,
+                 x, y, x of the link frames — every non-z axis goes through the loader's axis folding"""
 import sai2_primitives_perso_amd as pkg
 
 PANDA_LINKS = [dict(m=3, c=(0, 0, -0.07), i=(0.3, 0.3, 0.3)), dict(m=3, c=(0, -0.1, 0), i=(0.3, 0.3, 0.3)),
@@ -51,4 +54,22 @@ def planar_4r_urdf():
     return "\n".join(out)
 
 
-TEXT = {"sliding_base": sliding_base_urdf, "planar_4r": planar_4r_urdf}
+def six_r_urdf():
+    links = [dict(m=12.0, c=(0, 0, 0.05), i=(0.4, 0.4, 0.35)), dict(m=17.4, c=(0.07, 0, 0.2), i=(0.13, 0.52, 0.54)),
+             dict(m=4.8, c=(0.01, 0.02, 0.15), i=(0.066, 0.086, 0.0125)), dict(m=1.6, c=(0.02, 0, 0), i=(0.012, 0.009, 0.012)),
+             dict(m=1.1, c=(0, 0.01, 0), i=(0.006, 0.008, 0.006)), dict(m=0.8, c=(0.03, 0, 0), i=(0.004, 0.006, 0.006))]
+    xyz = [(0, 0, 0.67), (0, 0.15, 0), (0, 0, 0.43), (0.02, -0.02, 0.43), (0.1, 0, 0), (0.06, 0, 0)]
+    rpy = [(0, 0, 0), (0, 0, 0), (0, 0.1, 0), (0, 0, 0), (0.05, 0, 0), (0, 0, 0)]
+    axes = [(0, 0, 1), (0, 1, 0), (0, 1, 0), (1, 0, 0), (0, 1, 0), (1, 0, 0)]
+    lim = [(-2.8, 2.8), (-3.9, 0.8), (-0.9, 3.9), (-1.9, 2.9), (-1.7, 1.7), (-4.6, 4.6)]
+    eff = [97.6, 186.4, 89.4, 24.2, 20.1, 21.3]
+    out = ['<robot name="six_r">', _link("base", 10, (0, 0, 0.3), (0.5, 0.5, 0.2))]
+    for k, r in enumerate(links):
+        out.append(_link(f"link{k + 1}", r["m"], r["c"], r["i"]))
+    for k in range(6):
+        out.append(_joint(f"j{k + 1}", "revolute", "base" if k == 0 else f"link{k}", f"link{k + 1}", xyz[k], rpy[k], axes[k], lim[k][0], lim[k][1], eff[k]))
+    out.append("</robot>")
+    return "\n".join(out)
+
+
+TEXT = {"sliding_base": sliding_base_urdf, "planar_4r": planar_4r_urdf, "six_r": six_r_urdf}

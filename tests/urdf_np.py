@@ -33,8 +33,8 @@ def _axis_rot(a, q):
 
 
 class Chain:
-    def __init__(self, path):
-        root = ET.parse(path).getroot()
+    def __init__(self, path, is_file=True):
+        root = ET.parse(path).getroot() if is_file else ET.fromstring(path)
         self.links = {}
         for l in root.findall("link"):
             inn = l.find("inertial")
