@@ -69,3 +69,28 @@ def test_cert_kernel_c4_hierarchy_keeps_regular_robots(decoupling):
         assert e.max() < 1e-6
         # declined: the singular robots and a margin of near-singular ones (the certificate is sufficient, not necessary)
         assert sing.sum() <= g.fallback_count() <= sing.sum() + B // 20, (g.fallback_count(), sing.sum())
+
+
+def test_cert_kernel_backs_off_when_it_declines_most_of_the_batch():
+    """example 06's hierarchy on the sliding-base Panda ([partial JT(2), MFT(6), JT(8)]): most random poses are inside
+    a blending region, the SVD-free kernel would only add its own time in front of the generic one. The host sees
+    the count of declined robots (async read-back every 8th tick) and runs the generic kernel alone for a while;
+    results are the same either way. Also a one-robot batch through the same kernels."""
+    import test_gpu_robots as tr
+
+    m, kinds, o, g, q, dq = tr._setup("sliding_base", 512, False, False, seed=2)
+    seen = []
+    for tick in range(14):
+        tau_o, tau_g = o.tick(), g.tick()
+        sing = np.zeros(512, dtype=bool)
+        _, _, ro = o.get_mft_singularity(1)
+        sing |= ro < 6
+        sing |= g.get_singularity_types_count(1) > 0
+        e = _err(tau_g, tau_o)
+        assert e[~sing].max() < 1e-9 and e.max() < 1e-5, (tick, e.max())
+        seen.append(g.fallback_count())
+    assert seen[0] > 512 * 0.4 and seen[0] < 512, seen  # the kernel ran and declined most robots ...
+    assert seen[-1] == 512, seen  # ... and is being skipped by now
+    m, kinds, o, g, q, dq = tr._setup("six_r", 1, False, False, seed=5)
+    for tick in range(3):
+        assert _err(g.tick(), o.tick()).max() < 1e-9
