@@ -30,19 +30,24 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (FETCH_SIZE
-    and WRITE_SIZE are collected in separate passes and reported in KB; FETCH_SIZE under-reads coalesced
-    streams by 2x on gfx950: MI355X_MICROARCH.md §HBM). None when no summary is committed."""
+PMC_KERNEL = {2: "tick_fast_kernel<1", 3: "tick_fast_kernel<2", 4: "tick_cert_kernel", 5: "tick_fast_kernel<2"}
+
+
+def pmc_traffic_bytes(config):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this config's bench
+    command (profiles/r<round>_c<config>_counters.json, the latest round; FETCH_SIZE and WRITE_SIZE are collected in
+    separate passes and reported in KB; FETCH_SIZE under-reads coalesced streams by 2x on gfx950:
+    MI355X_MICROARCH.md §HBM). None when no summary is committed."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_*_counters.json")))
+    c = 3 if config == 5 else config
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_c{c}_counters.json")))
     if not files:
         return None
     data = json.load(open(files[-1]))
-    for name, c in data.items():
-        if "tick_fast_kernel<2" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            return (2 * c["FETCH_SIZE"]["avg_per_dispatch"] + c["WRITE_SIZE"]["avg_per_dispatch"]) * 1024
+    for name, cnt in data.items():
+        if PMC_KERNEL[config] in name and "FETCH_SIZE" in cnt and "WRITE_SIZE" in cnt:
+            return (2 * cnt["FETCH_SIZE"]["avg_per_dispatch"] + cnt["WRITE_SIZE"]["avg_per_dispatch"]) * 1024
     return None
 
 
@@ -209,7 +214,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_bytes() if args.config in (3, 5) and B == 65536 else None,
+                "traffic": pmc_traffic_bytes(args.config) if B == (65536 if args.config in (3, 5) else pkg.workloads.CONFIG_BATCH[args.config]) else None,
                 "kernel": {2: "sai2b::tick_fast_kernel<1>", 3: "sai2b::tick_fast_kernel<2>", 4: "sai2b::tick_cert_kernel<3>",
                            5: "sai2b::tick_fast_kernel<2>"}[args.config],
                 "kernel_ms": kernel_ms,
