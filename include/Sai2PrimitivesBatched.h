@@ -247,9 +247,16 @@ public:
 		for (int i = 0; i < SAI2B_MAX_DOF; i++) _cfg.kp[i] = kp, _cfg.kv[i] = kv, _cfg.ki[i] = ki;
 		syncConfig();
 	}
+	// JointTask.h:225-257 (JointTask.cpp:136-187): one gain per task coordinate, or vectors of size 1 = isotropic
+	void setGains(const std::vector<double>& kp, const std::vector<double>& kv, const std::vector<double>& ki) { gainsV(kp, kv, ki, true); }
+	void setGains(const std::vector<double>& kp, const std::vector<double>& kv) { gainsV(kp, kv, std::vector<double>(kp.size(), 0.0), true); }
+	void setGainsUnsafe(const std::vector<double>& kp, const std::vector<double>& kv, const std::vector<double>& ki) { gainsV(kp, kv, ki, false); }
+	// one entry when the gains are isotropic, task_dof otherwise (JointTask.cpp:207-216)
 	std::vector<PIDGains> getGains() const {
+		bool iso = true;
+		for (int i = 1; i < _cfg.task_dof; i++) iso = iso && _cfg.kp[i] == _cfg.kp[0] && _cfg.kv[i] == _cfg.kv[0] && _cfg.ki[i] == _cfg.ki[0];
 		std::vector<PIDGains> g;
-		for (int i = 0; i < _cfg.task_dof; i++) g.emplace_back(_cfg.kp[i], _cfg.kv[i], _cfg.ki[i]);
+		for (int i = 0; i < (iso ? 1 : _cfg.task_dof); i++) g.emplace_back(_cfg.kp[i], _cfg.kv[i], _cfg.ki[i]);
 		return g;
 	}
 	void enableVelocitySaturation(const double saturation_velocity) {
@@ -258,6 +265,27 @@ public:
 		for (int i = 0; i < SAI2B_MAX_DOF; i++) _cfg.saturation_velocity[i] = saturation_velocity;
 		syncConfig();
 	}
+	// JointTask.h:333 (JointTask.cpp:418-435): one value per task coordinate, or one for all
+	void enableVelocitySaturation(const std::vector<double>& saturation_velocity) {
+		if (saturation_velocity.size() == 1) return enableVelocitySaturation(saturation_velocity[0]);
+		if ((int)saturation_velocity.size() != _cfg.task_dof)
+			throw std::invalid_argument("saturation velocity vector size not consistent with task dof in JointTask::enableVelocitySaturation\n");
+		for (double v : saturation_velocity)
+			if (v <= 0) throw std::invalid_argument("saturation velocity must be positive in JointTask::enableVelocitySaturation\n");
+		_cfg.use_velocity_saturation = 1;
+		for (int i = 0; i < _cfg.task_dof; i++) _cfg.saturation_velocity[i] = saturation_velocity[i];
+		syncConfig();
+	}
+	std::vector<double> getVelocitySaturationMaxVelocity() const {	// JointTask.h:352
+		return std::vector<double>(_cfg.saturation_velocity, _cfg.saturation_velocity + _cfg.task_dof);
+	}
+	// JointTask.h:120: row-major task_dof x dof
+	std::vector<double> getJointSelectionMatrix() const {
+		return std::vector<double>(_cfg.joint_selection, _cfg.joint_selection + (size_t)_cfg.task_dof * _robot->dof());
+	}
+	// JointTask.h:130,151: S q and S dq of the state as it is now, [task_dof][B]
+	Batch getCurrentPosition() const { return selected(0); }
+	Batch getCurrentVelocity() const { return selected(1); }
 	void disableVelocitySaturation() {
 		_cfg.use_velocity_saturation = 0;
 		syncConfig();
@@ -272,6 +300,18 @@ public:
 		if (max_acceleration <= 0)
 			throw std::invalid_argument("max acceleration cannot be 0 or negative in any directions in OTG_joints::setMaxAcceleration\n");
 		for (int i = 0; i < SAI2B_MAX_DOF; i++) _cfg.otg_max_velocity[i] = max_velocity, _cfg.otg_max_acceleration[i] = max_acceleration;
+		_cfg.use_internal_otg = 1, _cfg.internal_otg_jerk_limited = 0;
+		syncConfig();
+	}
+	// JointTask.h:269: limits per task coordinate (OTG_joints.cpp:48-82 for the checks)
+	void enableInternalOtgAccelerationLimited(const std::vector<double>& max_velocity, const std::vector<double>& max_acceleration) {
+		if ((int)max_velocity.size() != _cfg.task_dof || (int)max_acceleration.size() != _cfg.task_dof)
+			throw std::invalid_argument("size of input max velocity / acceleration vector does not match task size in JointTask::enableInternalOtgAccelerationLimited\n");
+		for (int i = 0; i < _cfg.task_dof; i++) {
+			if (max_velocity[i] <= 0) throw std::invalid_argument("max velocity cannot be 0 or negative in any directions in OTG_joints::setMaxVelocity\n");
+			if (max_acceleration[i] <= 0) throw std::invalid_argument("max acceleration cannot be 0 or negative in any directions in OTG_joints::setMaxAcceleration\n");
+		}
+		for (int i = 0; i < _cfg.task_dof; i++) _cfg.otg_max_velocity[i] = max_velocity[i], _cfg.otg_max_acceleration[i] = max_acceleration[i];
 		_cfg.use_internal_otg = 1, _cfg.internal_otg_jerk_limited = 0;
 		syncConfig();
 	}
@@ -295,6 +335,33 @@ public:
 protected:
 	inline void flushGoals() override;
 	inline Batch desired(int which) const;
+	void gainsV(const std::vector<double>& kp, const std::vector<double>& kv, const std::vector<double>& ki, bool checked) {
+		const bool one = kp.size() == 1 && kv.size() == 1 && ki.size() == 1;
+		if (!one && ((int)kp.size() != _cfg.task_dof || (int)kv.size() != _cfg.task_dof || (int)ki.size() != _cfg.task_dof))
+			throw std::invalid_argument("size of gain vectors inconsistent with number of task dofs in JointTask::setGains\n");
+		if (checked) {	// the reference rejects only all-negative vectors (JointTask.cpp:171: maxCoeff() < 0); isotropic: any negative
+			double mp = kp[0], mv = kv[0], mi = ki[0];
+			for (size_t i = 1; i < kp.size(); i++) mp = std::max(mp, kp[i]), mv = std::max(mv, kv[i]), mi = std::max(mi, ki[i]);
+			if (one ? (kp[0] < 0 || kv[0] < 0 || ki[0] < 0) : (mp < 0 || mv < 0 || mi < 0))
+				throw std::invalid_argument("gains must be positive or zero in JointTask::setGains\n");
+		}
+		for (int i = 0; i < _cfg.task_dof; i++) _cfg.kp[i] = kp[one ? 0 : i], _cfg.kv[i] = kv[one ? 0 : i], _cfg.ki[i] = ki[one ? 0 : i];
+		if (!checked) _cfg.unsafe_motion_gains = 1;
+		syncConfig();
+	}
+	Batch selected(int which) const {
+		const int n = _robot->dof(), k0 = _cfg.task_dof;
+		const size_t b = B();
+		Batch x((size_t)n * b), out((size_t)k0 * b, 0.0);
+		detail::check(ctx(), sai2b_get_state(ctx(), which == 0 ? x.data() : nullptr, which == 1 ? x.data() : nullptr));
+		for (int i = 0; i < k0; i++)
+			for (int j = 0; j < n; j++) {
+				const double sij = _cfg.joint_selection[i * n + j];
+				if (sij != 0.0)
+					for (size_t r = 0; r < b; r++) out[i * b + r] += sij * x[j * b + r];
+			}
+		return out;
+	}
 	Batch goal(int which) const {
 		Batch out((size_t)_cfg.task_dof * B());
 		double* p[3] = {nullptr, nullptr, nullptr};
@@ -502,6 +569,23 @@ public:
 	inline std::vector<bool> goalOrientationReached(const double tolerance) const;
 	inline Batch getGoalPosition() const;
 	inline Batch getGoalOrientation() const;
+	// MotionForceTask.h:224-247: [3][B]
+	Batch getGoalLinearVelocity() const { return goalRow(2); }
+	Batch getGoalAngularVelocity() const { return goalRow(3); }
+	Batch getGoalLinearAcceleration() const { return goalRow(4); }
+	Batch getGoalAngularAcceleration() const { return goalRow(5); }
+	// MotionForceTask.h:369,385 (MotionForceTask.cpp:755-769): in the WORLD frame — a goal given in the compliant frame
+	// is turned by the frame's current orientation
+	Batch getGoalForce() const { return worldWrench(6); }
+	Batch getGoalMoment() const { return worldWrench(7); }
+	// MotionForceTask.h:173,183: the last sensor-frame readings handed to updateSensedForceAndMoment, [3][B]
+	Batch getSensedForceSensor() const { return _g[8].empty() ? Batch(3 * B(), 0.0) : _g[8]; }
+	Batch getSensedMomentSensor() const { return _g[9].empty() ? Batch(3 * B(), 0.0) : _g[9]; }
+	double getLinearSaturationVelocity() const { return _cfg.linear_saturation_velocity; }	 // MotionForceTask.h:437-440
+	double getAngularSaturationVelocity() const { return _cfg.angular_saturation_velocity; }
+	// MotionForceTask.h:653-659: the 3 x 3 diagonal blocks of the partial-task projection, row-major
+	std::vector<double> posSelectionProjector() const { return projectorBlock(0); }
+	std::vector<double> oriSelectionProjector() const { return projectorBlock(1); }
 	// MotionForceTask.cpp:988-1001
 	inline void resetIntegrators();
 	inline void resetIntegratorsLinear();
@@ -554,6 +638,29 @@ protected:
 	inline void flushGoals() override;
 	inline Batch desired(int which) const;
 	inline Batch status(int which) const;
+	Batch goalRow(int which) const {  // order of sai2b_get_mft_goals: pos rot v w a alpha force moment
+		Batch out((which == 1 ? 9 : 3) * B());
+		double* p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+		p[which] = out.data();
+		detail::check(ctx(), sai2b_get_mft_goals(ctx(), index(), p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]));
+		return out;
+	}
+	Batch worldWrench(int which) const {
+		Batch g = goalRow(which);
+		if (!_cfg.parametrization_in_compliant_frame) return g;
+		const Batch R = status(1);
+		const size_t b = B();
+		Batch out(3 * b);
+		for (size_t r = 0; r < b; r++)
+			for (int i = 0; i < 3; i++) out[i * b + r] = R[(3 * i) * b + r] * g[r] + R[(3 * i + 1) * b + r] * g[b + r] + R[(3 * i + 2) * b + r] * g[2 * b + r];
+		return out;
+	}
+	std::vector<double> projectorBlock(int blk) const {
+		std::vector<double> m(9);
+		for (int i = 0; i < 3; i++)
+			for (int j = 0; j < 3; j++) m[3 * i + j] = _cfg.partial_projection[(3 * blk + i) * 6 + 3 * blk + j];
+		return m;
+	}
 	void set(Batch& dst, const Batch& v, size_t rows, const char* what) {
 		checkRows(v, rows, what);
 		dst = v;

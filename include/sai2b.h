@@ -138,7 +138,8 @@ typedef struct sai2b_task_config {
 	double otg_max_angular_velocity, otg_max_angular_acceleration;
 
 	/* MotionForceTask::setPosControlGainsUnsafe / setOriControlGainsUnsafe (MotionForceTask.h:283,304;
-	 * MotionForceTask.cpp:630-649): nonzero skips the sign check of the motion gains */
+	 * MotionForceTask.cpp:630-649) and JointTask::setGainsUnsafe (JointTask.h:256, JointTask.cpp:136-156): nonzero
+	 * skips the sign check of the motion gains */
 	int unsafe_motion_gains;
 
 	/* joints of the robot the task is for (filled by the sai2b_default_* helpers; 0 is read as SAI2B_DOF) */

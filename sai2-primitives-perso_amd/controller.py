@@ -567,13 +567,37 @@ class JointTask(_TaskBase):
     def setGoalAcceleration(self, ddq):
         self._goal("ddq", ddq, self._cfg.task_dof)
 
-    def setGains(self, kp, kv, ki=0.0):
-        kp, kv, ki = (np.broadcast_to(np.asarray(x, dtype=float), (self._cfg.task_dof,)) for x in (kp, kv, ki))
-        if kp.min() < 0 or kv.min() < 0 or ki.min() < 0:
+    def setGains(self, kp, kv, ki=0.0, _checked=True):
+        """JointTask.h:225-257 (JointTask.cpp:136-205): scalars / size-1 vectors = isotropic, else one gain per task
+        coordinate; vectors are rejected only when every entry is negative (JointTask.cpp:171)"""
+        k0 = self._cfg.task_dof
+        a = [np.atleast_1d(np.asarray(x, dtype=float)) for x in (kp, kv, ki)]
+        iso = all(x.size == 1 for x in a)
+        if not iso:
+            a[2] = np.zeros(k0) if np.ndim(ki) == 0 and ki == 0.0 else a[2]  # the two-vector overload: ki = 0
+            if any(x.size != k0 for x in a):
+                raise ValueError("size of gain vectors inconsistent with number of task dofs in JointTask::setGains\n")
+        if _checked and (any(x[0] < 0 for x in a) if iso else any(x.max() < 0 for x in a)):
             raise ValueError("gains must be positive or zero in JointTask::setGains\n")
-        for i in range(self._cfg.task_dof):
+        kp, kv, ki = (np.broadcast_to(x, (k0,)) for x in a)
+        for i in range(k0):
             self._cfg.kp[i], self._cfg.kv[i], self._cfg.ki[i] = kp[i], kv[i], ki[i]
+        if not _checked:
+            self._cfg.unsafe_motion_gains = 1
         self._sync_cfg()
+
+    def setGainsUnsafe(self, kp, kv, ki):
+        """JointTask.h:256: no sign check"""
+        self.setGains(kp, kv, ki, _checked=False)
+
+    def getJointSelectionMatrix(self):
+        """JointTask.h:120: [task_dof, dof]"""
+        n = self._robot.dof()
+        return np.array(self._cfg.joint_selection[: self._cfg.task_dof * n]).reshape(self._cfg.task_dof, n)
+
+    def getVelocitySaturationMaxVelocity(self):
+        """JointTask.h:352"""
+        return np.array(self._cfg.saturation_velocity[: self._cfg.task_dof])
 
     def enableVelocitySaturation(self, saturation_velocity):
         v = np.broadcast_to(np.asarray(saturation_velocity, dtype=float), (self._cfg.task_dof,))
@@ -612,8 +636,10 @@ class JointTask(_TaskBase):
         return S @ rc._ctrl.get_state()[1]
 
     def getGains(self):
+        """one (kp, kv, ki) when the gains are isotropic, one per task coordinate otherwise (JointTask.cpp:207-216)"""
         k0 = self._cfg.task_dof
-        return [(self._cfg.kp[i], self._cfg.kv[i], self._cfg.ki[i]) for i in range(k0)]
+        g = [(self._cfg.kp[i], self._cfg.kv[i], self._cfg.ki[i]) for i in range(k0)]
+        return g[:1] if all(x == g[0] for x in g) else g
 
     def getTaskDof(self):
         return self._cfg.task_dof
@@ -721,6 +747,14 @@ class MotionForceTask(_TaskBase):
     def updateSensedForceAndMoment(self, f, m):
         self._goal("sf", f, 3)
         self._goal("sm", m, 3)
+        self._sensed_sensor = (f, m)
+
+    def getSensedForceSensor(self):
+        """MotionForceTask.h:173,183: the last sensor-frame readings handed to updateSensedForceAndMoment"""
+        return getattr(self, "_sensed_sensor", (np.zeros((3, self._robot.batch)),) * 2)[0]
+
+    def getSensedMomentSensor(self):
+        return getattr(self, "_sensed_sensor", (np.zeros((3, self._robot.batch)),) * 2)[1]
 
     def _set3(self, names, values, where):
         vals = [np.broadcast_to(np.asarray(v, dtype=float), (3,)) for v in values]
@@ -891,13 +925,51 @@ class MotionForceTask(_TaskBase):
         rc, idx = self._require_owner()
         return rc._ctrl.get_mft_goals(idx)[1]
 
-    def getGoalForce(self):
+    def _world_wrench(self, which):
+        """MotionForceTask.cpp:755-769: a goal given in the compliant frame comes back in the WORLD frame"""
         rc, idx = self._require_owner()
-        return rc._ctrl.get_mft_goals(idx)[6]
+        g = rc._ctrl.get_mft_goals(idx)[which]
+        if not self._cfg.parametrization_in_compliant_frame:
+            return g
+        R = self._status()["rot"].T.reshape(-1, 3, 3)
+        return np.ascontiguousarray(np.einsum("bij,jb->ib", R, g))
+
+    def getGoalForce(self):
+        return self._world_wrench(6)
 
     def getGoalMoment(self):
+        return self._world_wrench(7)
+
+    def getGoalLinearVelocity(self):
+        """MotionForceTask.h:224-247"""
         rc, idx = self._require_owner()
-        return rc._ctrl.get_mft_goals(idx)[7]
+        return rc._ctrl.get_mft_goals(idx)[2]
+
+    def getGoalAngularVelocity(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_goals(idx)[3]
+
+    def getGoalLinearAcceleration(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_goals(idx)[4]
+
+    def getGoalAngularAcceleration(self):
+        rc, idx = self._require_owner()
+        return rc._ctrl.get_mft_goals(idx)[5]
+
+    def getLinearSaturationVelocity(self):
+        """MotionForceTask.h:437-440"""
+        return self._cfg.linear_saturation_velocity
+
+    def getAngularSaturationVelocity(self):
+        return self._cfg.angular_saturation_velocity
+
+    def posSelectionProjector(self):
+        """MotionForceTask.h:653-659: 3 x 3 diagonal blocks of the partial-task projection"""
+        return np.array(self._cfg.partial_projection[:]).reshape(6, 6)[:3, :3].copy()
+
+    def oriSelectionProjector(self):
+        return np.array(self._cfg.partial_projection[:]).reshape(6, 6)[3:, 3:].copy()
 
     def setSingularityHandlingGains(self, kp_type_1, kv_type_1, kv_type_2):
         """MotionForceTask.h:748-753"""

@@ -357,7 +357,7 @@ extern "C" int sai2b_validate_tasks(const sai2b_task_config* tasks, int n_tasks,
 				err = "joint selection matrix is not full rank in JointTask constructor\n";
 			else if (t.task_dof == N)
 				closed = true;	// isFullJointTask (RobotController.cpp:44-49)
-			for (int k = 0; err.empty() && k < t.task_dof; k++)
+			for (int k = 0; err.empty() && k < t.task_dof && !t.unsafe_motion_gains; k++)	// (setGainsUnsafe: JointTask.cpp:136-156)
 				if (t.kp[k] < 0 || t.kv[k] < 0 || t.ki[k] < 0) err = "gains must be positive or zero in JointTask::setGains\n";
 		}
 		if (err.empty() && t.type == SAI2B_MOTION_FORCE_TASK) {

@@ -71,6 +71,29 @@ static int validate() {
 			   JointTask t(robot);
 			   t.setGoalPosition(Batch(3, 0.0));
 		   }, "size not consistent"), "goal size");
+	{	// accessors of the reference that need no device (JointTask.h:120,225-257,333-354; MotionForceTask.h:437-440,653-659)
+		std::vector<double> sel(14, 0.0);
+		sel[1] = 1, sel[7 + 4] = 1;
+		JointTask t(robot, sel, 2);
+		t.setGains(30.0, 8.0, 1.0);
+		expect(t.getGains().size() == 1 && t.getGains()[0].kp == 30.0 && t.getGains()[0].ki == 1.0, "isotropic gains come back as one entry");
+		t.setGains(std::vector<double>{10, 20}, std::vector<double>{1, 2});
+		expect(t.getGains().size() == 2 && t.getGains()[1].kp == 20.0 && t.getGains()[1].ki == 0.0, "one gain per task coordinate");
+		expect(throws_invalid([&] { t.setGains(std::vector<double>{1, 2, 3}, std::vector<double>{1, 2, 3}); }, "inconsistent with number of task dofs"), "gain vector size");
+		expect(throws_invalid([&] { t.setGains(std::vector<double>{-1, -2}, std::vector<double>{1, 2}); }, "positive or zero"), "all-negative gain vector");
+		t.setGainsUnsafe(std::vector<double>{-1, 5}, std::vector<double>{1, 2}, std::vector<double>{0, 0});
+		expect(t.getGains()[0].kp == -1.0, "unsafe gains skip the sign check");
+		expect(t.getJointSelectionMatrix() == sel, "joint selection matrix");
+		t.enableVelocitySaturation(std::vector<double>{0.3, 0.6});
+		expect(t.getVelocitySaturationMaxVelocity() == std::vector<double>({0.3, 0.6}), "per-coordinate saturation velocities");
+		expect(throws_invalid([&] { t.enableVelocitySaturation(std::vector<double>{0.3, 0.0}); }, "must be positive"), "zero saturation velocity");
+		expect(throws_invalid([&] { t.enableInternalOtgAccelerationLimited(std::vector<double>{1.0}, std::vector<double>{1.0, 1.0}); }, "does not match task size"), "otg limit vector size");
+		MotionForceTask m(robot, 6, std::vector<double>{1, 0, 0, 0, 1, 0}, std::vector<double>{0, 0, 1}, pos);
+		const std::vector<double> pp = m.posSelectionProjector(), po = m.oriSelectionProjector();
+		expect(pp[0] == 1 && pp[4] == 1 && pp[8] == 0 && po[8] == 1 && po[0] == 0, "selection projectors of a partial task");
+		m.enableVelocitySaturation(0.25, 0.5);
+		expect(m.getLinearSaturationVelocity() == 0.25 && m.getAngularSaturationVelocity() == 0.5, "saturation velocities");
+	}
 	std::printf(fails ? "validate: %d failures\n" : "validate: ok\n", fails);
 	return fails;
 }

@@ -383,6 +383,30 @@ def test_facade_mirrors_reference_api():
     assert mft.parametrizeMomentRotMotionSpaces(0) is False
     assert np.abs(mft.getGoalPosition() - mft.getCurrentPosition()).max() < 1e-12
     assert mft.parametrizeForceMotionSpaces(0) is True
+    # goal / state getters of the reference (MotionForceTask.h:173-247,369-385,437-440,653-659; JointTask.h:120-151,207-216)
+    assert np.array_equal(mft.getGoalLinearVelocity(), np.zeros((3, B)))  # zeroed with the re-parametrised half
+    assert np.array_equal(mft.getGoalAngularVelocity(), g0["w"]) and np.array_equal(mft.getGoalAngularAcceleration(), g0["alpha"])
+    gf = np.random.default_rng(2).normal(size=(3, B))
+    mft.setGoalForce(gf)
+    assert np.array_equal(mft.getGoalForce(), gf)  # world-frame parametrisation: as given
+    mft2 = pkg.MotionForceTask(robot, task_name="ee_frame", is_force_motion_parametrization_in_compliant_frame=True)
+    ctl2 = pkg.RobotController(robot, [mft2])
+    mft2.setGoalForce(gf)
+    R = mft2.getCurrentOrientation().T.reshape(B, 3, 3)
+    assert np.abs(mft2.getGoalForce() - np.einsum("bij,jb->ib", R, gf)).max() < 1e-14  # compliant frame: turned into the world
+    sf, sm = np.random.default_rng(3).normal(size=(2, 3, B))
+    mft.updateSensedForceAndMoment(sf, sm)
+    assert np.array_equal(mft.getSensedForceSensor(), sf) and np.array_equal(mft.getSensedMomentSensor(), sm)
+    assert np.array_equal(mft.posSelectionProjector(), np.eye(3)) and mft.getLinearSaturationVelocity() > 0
+    assert np.array_equal(jt.getCurrentVelocity(), inp["dq"]) and np.array_equal(jt.getJointSelectionMatrix(), np.eye(7))
+    assert len(jt.getGains()) == 1
+    jt.setGains(np.arange(1.0, 8.0), np.ones(7))
+    assert len(jt.getGains()) == 7 and jt.getGains()[6][0] == 7.0
+    with pytest.raises(ValueError, match="inconsistent with number of task dofs"):
+        jt.setGains(np.ones(3), np.ones(3))
+    jt.setGainsUnsafe(-np.ones(7), np.ones(7), np.zeros(7))
+    assert jt.getGains()[0][0] == -1.0
+    del ctl2
     with pytest.raises(ValueError):
         jt.setGoalPosition(np.zeros((3, B)))
     with pytest.raises(ValueError, match="same robot model"):
