@@ -116,6 +116,15 @@ private:
 // reference src/tasks/TemplateTask.h:25-123
 class TemplateTask {
 public:
+	// OTG_joints / OTG_6dof_cartesian::isGoalReached() of this task's internal generator, per robot
+	std::vector<bool> otgGoalReached() const {
+		std::vector<double> r(B());
+		detail::check(ctx(), sai2b_get_otg_status(ctx(), index(), r.data(), nullptr));
+		std::vector<bool> out(r.size());
+		for (size_t i = 0; i < r.size(); i++) out[i] = r[i] != 0.0;
+		return out;
+	}
+
 	TemplateTask(std::shared_ptr<BatchedRobotModel>& robot, const TaskType task_type)
 		: _robot(robot), _task_type(task_type), _q_construction(robot->q()) {}
 	virtual ~TemplateTask() { releaseOwnContext(); }
@@ -323,6 +332,21 @@ public:
 		syncConfig();
 	}
 	bool getInternalOtgEnabled() const { return _cfg.use_internal_otg != 0; }
+	// JointTask.h:324 `const OTG_joints& getInternalOtg() const`: the read-only side of OTG_joints
+	// (OTG_joints.h:110-164), one answer per robot
+	class InternalOtg {
+	public:
+		explicit InternalOtg(const JointTask* t) : _t(t) {}
+		std::vector<bool> isGoalReached() const { return _t->otgGoalReached(); }
+		bool getJerkLimitEnabled() const { return false; }
+		Batch getNextPosition() const { return _t->getDesiredPosition(); }
+		Batch getNextVelocity() const { return _t->getDesiredVelocity(); }
+		Batch getNextAcceleration() const { return _t->getDesiredAcceleration(); }
+
+	private:
+		const JointTask* _t;
+	};
+	InternalOtg getInternalOtg() const { return InternalOtg(this); }
 	// JointTask.h:144-160: [task_dof][B]
 	Batch getGoalPosition() const { return goal(0); }
 	Batch getGoalVelocity() const { return goal(1); }
@@ -504,6 +528,24 @@ public:
 		syncConfig();
 	}
 	bool getInternalOtgEnabled() const { return _cfg.use_internal_otg != 0; }
+	// MotionForceTask.h `const OTG_6dof_cartesian& getInternalOtg() const`: the read-only side of
+	// OTG_6dof_cartesian (OTG_6dof_cartesian.h:171-243), one answer per robot
+	class InternalOtg {
+	public:
+		explicit InternalOtg(const MotionForceTask* t) : _t(t) {}
+		std::vector<bool> isGoalReached() const { return _t->otgGoalReached(); }
+		bool getJerkLimitEnabled() const { return false; }
+		Batch getNextPosition() const { return _t->getDesiredPosition(); }
+		Batch getNextOrientation() const { return _t->getDesiredOrientation(); }
+		Batch getNextLinearVelocity() const { return _t->getDesiredLinearVelocity(); }
+		Batch getNextAngularVelocity() const { return _t->getDesiredAngularVelocity(); }
+		Batch getNextLinearAcceleration() const { return _t->getDesiredLinearAcceleration(); }
+		Batch getNextAngularAcceleration() const { return _t->getDesiredAngularAcceleration(); }
+
+	private:
+		const MotionForceTask* _t;
+	};
+	InternalOtg getInternalOtg() const { return InternalOtg(this); }
 	// goal, or the OTG's next state: position/velocities/accelerations [3][B], orientation [9][B]
 	inline Batch getDesiredPosition() const;
 	inline Batch getDesiredOrientation() const;

@@ -465,6 +465,45 @@ class _StandaloneOwner:
         robot._standalone.append(self)
 
 
+class _InternalOtgView:
+    """read-only side of the task's OTG_joints / OTG_6dof_cartesian object (JointTask.h:324 `getInternalOtg()`,
+    OTG_joints.h:110-164, OTG_6dof_cartesian.h:171-243): one answer per robot"""
+
+    def __init__(self, task):
+        self._t = task
+
+    def isGoalReached(self):
+        rc, idx = self._t._require_owner()
+        return rc._ctrl.get_otg_status(idx)[0] != 0
+
+    def getJerkLimitEnabled(self):
+        return False
+
+    def getNextPosition(self):
+        return self._t.getDesiredPosition()
+
+    def getNextVelocity(self):
+        return self._t.getDesiredVelocity()
+
+    def getNextAcceleration(self):
+        return self._t.getDesiredAcceleration()
+
+    def getNextOrientation(self):
+        return self._t.getDesiredOrientation()
+
+    def getNextLinearVelocity(self):
+        return self._t.getDesiredLinearVelocity()
+
+    def getNextAngularVelocity(self):
+        return self._t.getDesiredAngularVelocity()
+
+    def getNextLinearAcceleration(self):
+        return self._t.getDesiredLinearAcceleration()
+
+    def getNextAngularAcceleration(self):
+        return self._t.getDesiredAngularAcceleration()
+
+
 class _TaskBase:
     def __init__(self, robot, cfg):
         self._robot = robot
@@ -475,6 +514,9 @@ class _TaskBase:
         self._task_level = False  # the last model update came through updateTaskModel()
 
     # TemplateTask accessors (reference src/tasks/TemplateTask.h:95-115)
+    def getInternalOtg(self):
+        return _InternalOtgView(self)
+
     def getTaskName(self):
         return self._cfg.name.decode()
 

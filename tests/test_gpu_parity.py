@@ -400,6 +400,9 @@ def test_facade_mirrors_reference_api():
     assert np.array_equal(mft.posSelectionProjector(), np.eye(3)) and mft.getLinearSaturationVelocity() > 0
     assert np.array_equal(jt.getCurrentVelocity(), inp["dq"]) and np.array_equal(jt.getJointSelectionMatrix(), np.eye(7))
     assert len(jt.getGains()) == 1
+    otg = jt.getInternalOtg()  # JointTask.h:324: the read-only side of the generator object
+    assert otg.isGoalReached().shape == (B,) and not otg.getJerkLimitEnabled()
+    assert np.array_equal(otg.getNextPosition(), jt.getDesiredPosition())
     jt.setGains(np.arange(1.0, 8.0), np.ones(7))
     assert len(jt.getGains()) == 7 and jt.getGains()[6][0] == 7.0
     with pytest.raises(ValueError, match="inconsistent with number of task dofs"):

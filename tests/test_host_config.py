@@ -129,3 +129,23 @@ def test_workload_generator_is_deterministic_and_in_range():
     c = pkg.workloads.make_inputs(5, B=64, rank=1)
     d = pkg.workloads.make_inputs(5, B=64, rank=0)
     assert not np.array_equal(c["q"], d["q"])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/tasks"), reason="reference tree not present")
+def test_facades_carry_every_public_member_name_of_the_reference_headers():
+    """the drop-in boundary by NAME: every camelCase member function the reference declares in RobotController.h,
+    TemplateTask.h, JointTask.h and MotionForceTask.h exists in the C++ facade and in the Python mirror (signatures
+    differ where Eigen types become batched arrays; `initialSetup` is the reference's private constructor helper)"""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cpp = open(os.path.join(root, "include", "Sai2PrimitivesBatched.h")).read()
+    py = open(os.path.join(root, "sai2-primitives-perso_amd", "controller.py")).read()
+    missing = []
+    for h in ("RobotController.h", "tasks/TemplateTask.h", "tasks/JointTask.h", "tasks/MotionForceTask.h"):
+        txt = open(os.path.join("/root/reference/src", h)).read()
+        for name in set(re.findall(r"\b([a-z][a-zA-Z0-9]*[A-Z][a-zA-Z0-9]*)\s*\(", txt)) - {"initialSetup", "setZero"}:
+            for where, text in (("C++", cpp), ("Python", py)):
+                if not re.search(r"\b" + name + r"\b", text):
+                    missing.append((h, name, where))
+    assert not missing, missing
