@@ -4,6 +4,7 @@
 //   facade_test tick <B> <in>   (GPU)    reads q,dq,goals (raw doubles) from <in>, prints torques
 //   facade_test example04 <B> <in> <ticks> / example01 <B> <in> <ticks>   (GPU) the reference's examples 04 and 01,
 //                               tasks driven through the TemplateTask virtuals with no RobotController
+//   facade_test example18 <B> <in> <ticks>   (GPU) example 18: the Panda driven into its singularities
 //   facade_test example06 <B> <urdf> <in> <ticks>   (GPU) example 06: the 8-joint sliding-base Panda from its URDF
 #include <cmath>
 #include <cstdio>
@@ -317,10 +318,69 @@ static int example06(int B, const char* urdf, const char* path, int ticks) {
 	return 0;
 }
 
+// examples/18-panda_singularity/18-panda_singularity.cpp:104-228 call for call: a full MotionForceTask with velocity
+// saturation and a JointTask behind it, nullspaces chained by hand, position goals 2 m outside the workspace in
+// +x, +y, -y, +z (back to the start in between), so that the arm stretches into its elbow / wrist singularities and
+// the SingularityHandler blends the type-1 / type-2 strategies in and out. The waits between goals are compressed
+// to `ticks / 8` periods. Prints, per period: the state read from the simulation (q, dq) and the control torques.
+static int example18(int B, const char* path, int ticks) {
+	std::ifstream f(path, std::ios::binary);
+	Batch q0(7 * (size_t)B), dq0(7 * (size_t)B, 0.0);
+	f.read((char*)q0.data(), q0.size() * sizeof(double));
+	auto robot = std::make_shared<BatchedRobotModel>(B);
+	robot->setQ(q0);
+	robot->setDq(dq0);
+	robot->updateModel();  // :107
+	const double pos_in_link[3] = {0.0, 0.0, 0.22};	 // "end-effector" (0, 0, 0.07) seen from link7 (:112-114)
+	auto motion_force_task = std::make_unique<MotionForceTask>(robot, 6, pos_in_link);	// :117-118
+	motion_force_task->disableInternalOtg();											// :129
+	motion_force_task->enableVelocitySaturation();										// :130
+	const Batch initial_position = motion_force_task->getCurrentPosition();				// :135
+	auto joint_task = std::make_unique<JointTask>(robot);								// :139
+	joint_task->setGains(100, 20);														// :140
+	const Batch initial_q = robot->q();													// :143
+	joint_task->setGoalPosition(initial_q);												// :144
+	const double desired_offsets[8][3] = {{2, 0, 0}, {0, 0, 0}, {0, 2, 0}, {0, 0, 0}, {0, -2, 0}, {0, 0, 0}, {0, 0, 2}, {0, 0, 0}};  // :147-150
+	const int wait = ticks / 8, max_cnt = 8;
+	int cnt = 0, prev = -wait;
+	BatchedSimulation sim(*motion_force_task, 0.001, 2);  // the example's 2 kHz simulation thread (:236-241)
+	const Batch zero3(3 * (size_t)B, 0.0);
+	for (int cycle = 0; cycle < ticks; cycle++) {
+		const Batch q = sim.getJointPositions(), dq = sim.getJointVelocities();
+		std::fwrite(q.data(), sizeof(double), q.size(), stdout);
+		std::fwrite(dq.data(), sizeof(double), dq.size(), stdout);
+		robot->setQ(q);	 // :176-178
+		robot->setDq(dq);
+		robot->updateModel();
+		motion_force_task->updateTaskModel();									// :181-185 N_prec = identity
+		const Batch N_prec = motion_force_task->getTaskAndPreviousNullspace();	// :186
+		joint_task->updateTaskModel(N_prec);									// :191
+		if (cycle - prev >= wait) {												// :195-201
+			Batch goal(3 * (size_t)B);
+			for (int i = 0; i < 3; i++)
+				for (int b = 0; b < B; b++) goal[(size_t)i * B + b] = initial_position[(size_t)i * B + b] + desired_offsets[cnt][i];
+			motion_force_task->setGoalPosition(goal);
+			cnt++;
+			prev = cycle;
+			if (cnt == max_cnt) cnt = max_cnt - 1;
+		}
+		motion_force_task->setGoalLinearVelocity(zero3);	  // :202-203
+		motion_force_task->setGoalLinearAcceleration(zero3);
+		const Batch motion_force_task_torques = motion_force_task->computeTorques();  // :206
+		const Batch joint_task_torques = joint_task->computeTorques();				   // :207
+		const Batch control_torques = add(motion_force_task_torques, joint_task_torques);  // :212
+		std::fwrite(control_torques.data(), sizeof(double), control_torques.size(), stdout);
+		sim.setJointTorques(control_torques);
+		sim.integrate();
+	}
+	return 0;
+}
+
 int main(int argc, char** argv) {
 	try {
 		if (argc >= 6 && std::strcmp(argv[1], "example06") == 0) return example06(std::atoi(argv[2]), argv[3], argv[4], std::atoi(argv[5]));
 		if (argc >= 5 && std::strcmp(argv[1], "example04") == 0) return example04(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
+		if (argc >= 5 && std::strcmp(argv[1], "example18") == 0) return example18(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example01") == 0) return example01(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 2 && std::strcmp(argv[1], "validate") == 0) return validate();
 		if (argc >= 4 && std::strcmp(argv[1], "tick") == 0) return tick(std::atoi(argv[2]), argv[3]);
