@@ -432,6 +432,20 @@ public:
 		_cfg.parametrization_in_compliant_frame = is_force_motion_parametrization_in_compliant_frame;
 		_cfg.loop_timestep = loop_timestep;
 	}
+	// MotionForceTask.h:103-110 with the link given by NAME (examples/11-planar_robot_controller.cpp:105-115)
+	MotionForceTask(std::shared_ptr<BatchedRobotModel>& robot, const std::string& link_name, const std::vector<double>& controlled_directions_translation,
+					const std::vector<double>& controlled_directions_rotation, const double compliant_frame_pos[3],
+					const double* compliant_frame_rot = nullptr, const std::string& task_name = "partial_motion_force_task",
+					const bool is_force_motion_parametrization_in_compliant_frame = false, const double loop_timestep = 0.001)
+		: TemplateTask(robot, MOTION_FORCE_TASK) {
+		double fp[3], fr[9];
+		const int link = robot->resolveLink(link_name, compliant_frame_pos, compliant_frame_rot, fp, fr);
+		detail::check(nullptr, sai2b_default_motion_force_task_dof(&_cfg, task_name.c_str(), robot->dof(), link, fp, fr,
+																   (int)controlled_directions_translation.size() / 3, controlled_directions_translation.data(),
+																   (int)controlled_directions_rotation.size() / 3, controlled_directions_rotation.data()));
+		_cfg.parametrization_in_compliant_frame = is_force_motion_parametrization_in_compliant_frame;
+		_cfg.loop_timestep = loop_timestep;
+	}
 	// MotionForceTask.h:211-247; positions/velocities/accelerations [3][B], orientation [9][B] row-major
 	void setGoalPosition(const Batch& v) { set(_g[0], v, 3, "goal position"); }
 	void setGoalOrientation(const Batch& v) { set(_g[1], v, 9, "goal orientation"); }

@@ -5,6 +5,7 @@
 //   facade_test example04 <B> <in> <ticks> / example01 <B> <in> <ticks>   (GPU) the reference's examples 04 and 01,
 //                               tasks driven through the TemplateTask virtuals with no RobotController
 //   facade_test example18 <B> <in> <ticks>   (GPU) example 18: the Panda driven into its singularities
+//   facade_test example11 <B> <urdf> <in> <ticks>   (GPU) example 11: the planar 4R from its URDF, RobotController
 //   facade_test example06 <B> <urdf> <in> <ticks>   (GPU) example 06: the 8-joint sliding-base Panda from its URDF
 #include <cmath>
 #include <cstdio>
@@ -376,10 +377,68 @@ static int example18(int B, const char* path, int ticks) {
 	return 0;
 }
 
+// examples/11-planar_robot_controller/11-planar_robot_controller.cpp:99-166 call for call: the planar 4R read from its
+// URDF, a partial MotionForceTask (x, y, rotation about z) on "link4" given by name and a JointTask behind it in a
+// RobotController, both with the reference's default internal OTG left on; the goal steps of cycles 0 / 2000 of
+// 4000 compressed to 0 / ticks/2. Prints, per period, the state read (q, dq) and the control torques.
+static int example11(int B, const char* urdf, const char* path, int ticks) {
+	auto robot = std::make_shared<BatchedRobotModel>(std::string(urdf), B);
+	const int dof = robot->dof();
+	std::ifstream f(path, std::ios::binary);
+	Batch q0((size_t)dof * B), dq0((size_t)dof * B, 0.0);
+	f.read((char*)q0.data(), q0.size() * sizeof(double));
+	robot->setQ(q0);
+	robot->setDq(dq0);
+	robot->updateModel();  // :101
+	const double frame_pos[3] = {0.5, 0.0, 0.0};								  // :106-107
+	const std::vector<double> controlled_directions_translation = {1, 0, 0, 0, 1, 0};	  // :108-110
+	const std::vector<double> controlled_directions_rotation = {0, 0, 1};				  // :111-112
+	auto motion_force_task = std::make_shared<MotionForceTask>(robot, std::string("link4"), controlled_directions_translation,
+																controlled_directions_rotation, frame_pos);	 // :113-115
+	const Batch initial_orientation = motion_force_task->getCurrentOrientation();  // :118-120
+	const Batch initial_position = motion_force_task->getCurrentPosition();
+	Batch goal_position = initial_position, goal_orientation = initial_orientation;
+	auto joint_task = std::make_shared<JointTask>(robot);													 // :125
+	std::vector<std::shared_ptr<TemplateTask>> task_list = {motion_force_task, joint_task};				 // :126-127
+	auto robot_controller = std::make_unique<RobotController>(robot, task_list);							 // :128-129
+	BatchedSimulation sim(*robot_controller, 0.001, 2);
+	const double c = std::cos(-M_PI / 4), s_ = std::sin(-M_PI / 4);
+	for (int cycle = 0; cycle < ticks; cycle++) {
+		const Batch q = sim.getJointPositions(), dq = sim.getJointVelocities();
+		std::fwrite(q.data(), sizeof(double), q.size(), stdout);
+		std::fwrite(dq.data(), sizeof(double), dq.size(), stdout);
+		robot->setQ(q);	 // :139-141
+		robot->setDq(dq);
+		robot->updateModel();
+		robot_controller->updateControllerTaskModels();	 // :144
+		if (cycle % ticks == 0) {						 // :147-149
+			goal_position = initial_position;
+			goal_orientation = initial_orientation;
+		} else if (cycle % ticks == ticks / 2) {  // :150-154: back by (0.25, 0.25, 0), turned by -pi/4 about z
+			for (int b = 0; b < B; b++) {
+				goal_position[(size_t)0 * B + b] = initial_position[(size_t)0 * B + b] - 0.25;
+				goal_position[(size_t)1 * B + b] = initial_position[(size_t)1 * B + b] - 0.25;
+				for (int j = 0; j < 3; j++) {
+					const double r0 = initial_orientation[(size_t)j * B + b], r1 = initial_orientation[(size_t)(3 + j) * B + b];
+					goal_orientation[(size_t)j * B + b] = c * r0 - s_ * r1;
+					goal_orientation[(size_t)(3 + j) * B + b] = s_ * r0 + c * r1;
+				}
+			}
+		}
+		motion_force_task->setGoalPosition(goal_position);		 // :156-157
+		motion_force_task->setGoalOrientation(goal_orientation);
+		const Batch control_torques = robot_controller->computeControlTorques();  // :162
+		std::fwrite(control_torques.data(), sizeof(double), control_torques.size(), stdout);
+		sim.integrate();
+	}
+	return 0;
+}
+
 int main(int argc, char** argv) {
 	try {
 		if (argc >= 6 && std::strcmp(argv[1], "example06") == 0) return example06(std::atoi(argv[2]), argv[3], argv[4], std::atoi(argv[5]));
 		if (argc >= 5 && std::strcmp(argv[1], "example04") == 0) return example04(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
+		if (argc >= 6 && std::strcmp(argv[1], "example11") == 0) return example11(std::atoi(argv[2]), argv[3], argv[4], std::atoi(argv[5]));
 		if (argc >= 5 && std::strcmp(argv[1], "example18") == 0) return example18(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example01") == 0) return example01(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 2 && std::strcmp(argv[1], "validate") == 0) return validate();

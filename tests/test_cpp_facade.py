@@ -265,3 +265,58 @@ def test_cpp_example_18_panda_singularity(facade_bin, tmp_path):
     assert worst_regular < 1e-9, worst_regular
     # (measured: 57 204 robot-periods inside a blending region, worst 2.7e-13 there, none above 1e-5)
     assert worst_singular < 1e-6 and big == 0, (big, singular_periods, worst_singular)
+
+
+@pytest.mark.gpu
+def test_cpp_example_11_planar_robot_controller(facade_bin, tmp_path):
+    """tests/cpp/facade_test.cpp::example11 = examples/11-planar_robot_controller.cpp:99-166 call for call: the planar 4R
+    from its URDF, partial MotionForceTask (x, y, rotation about z) on a link given by NAME + JointTask in a
+    RobotController, the reference's default internal OTG of both tasks left ON (the goal steps are followed along
+    generated trajectories). The oracle gets the state the program read each period and makes the same calls."""
+    import oracle_lib as ol
+    import robots
+
+    B, ticks = 64, 400
+    urdf = tmp_path / "rrrrbot.urdf"
+    urdf.write_text(robots.TEXT["planar_4r"]())
+    m, links = pkg.model_from_urdf(str(urdf))
+    n = m.dof
+    rng = np.random.default_rng(11)
+    q0 = np.array([0.4, -0.7, 0.9, -0.6])[:, None] + rng.normal(0, 0.15, (n, B))
+    path = tmp_path / "q.bin"
+    np.ascontiguousarray(q0).tofile(path)
+    r = subprocess.run([facade_bin, "example11", str(B), str(urdf), str(path), str(ticks)], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    out = np.frombuffer(r.stdout, dtype=np.float64).reshape(ticks, 3, n, B)
+    link, fpos, frot = pkg.resolve_link_frame(links, "link4", (0.5, 0.0, 0.0))
+    partial = (np.array([[1.0, 0, 0], [0, 1.0, 0]]), np.array([[0, 0, 1.0]]))
+    cfg = [ol.motion_force_task("partial_motion_force_task", link, fpos, frot, partial, internal_otg=True, robot_dof=n),
+           ol.joint_task("joint_task", None, internal_otg=True, robot_dof=n)]
+    o = ol.Oracle(m, cfg, B, threads=8)
+    o.set_state(q0, np.zeros_like(q0))
+    o.reinitialize()
+    st = o.get_mft_status(0)
+    x0, R0 = st["pos"].copy(), st["rot"].reshape(3, 3, B).copy()
+    c, s = np.cos(-np.pi / 4), np.sin(-np.pi / 4)
+    Rz = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+    gp, gR = x0, R0.reshape(9, B)
+    worst, moved = 0.0, 0.0
+    for cycle in range(ticks):
+        q, dq, tau_g = out[cycle]
+        o.set_state(q, dq)
+        o.update_task_models()
+        if cycle % ticks == 0:
+            gp, gR = x0, R0.reshape(9, B)
+        elif cycle % ticks == ticks // 2:
+            gp = x0 - np.array([0.25, 0.25, 0.0])[:, None]
+            gR = np.einsum("ik,kjb->ijb", Rz, R0).reshape(9, B)
+        o.set_mft_goals(0, gp, np.ascontiguousarray(gR), None, None, None, None)
+        tau = o.compute_control_torques(True)
+        _, _, ro = o.get_mft_singularity(0)
+        reg = ro == 3
+        e = np.abs(tau_g - tau).max(axis=0) / np.maximum(np.abs(tau).max(axis=0), 1)
+        worst = max(worst, e[reg].max(initial=0.0))
+        assert e.max() < 1e-5, (cycle, e.max())
+        moved = max(moved, np.abs(q - q0).max())
+    assert worst < 1e-9, worst
+    assert moved > 0.1  # the generators carried the arm towards the stepped goal
