@@ -4,6 +4,7 @@
 //   facade_test tick <B> <in>   (GPU)    reads q,dq,goals (raw doubles) from <in>, prints torques
 //   facade_test example04 <B> <in> <ticks> / example01 <B> <in> <ticks>   (GPU) the reference's examples 04 and 01,
 //                               tasks driven through the TemplateTask virtuals with no RobotController
+//   facade_test example02 <B> <in> <ticks>   (GPU) example 02: JointTask with the acceleration-limited internal OTG
 //   facade_test example18 <B> <in> <ticks>   (GPU) example 18: the Panda driven into its singularities
 //   facade_test example11 <B> <urdf> <in> <ticks>   (GPU) example 11: the planar 4R from its URDF, RobotController
 //   facade_test example06 <B> <urdf> <in> <ticks>   (GPU) example 06: the 8-joint sliding-base Panda from its URDF
@@ -377,6 +378,58 @@ static int example18(int B, const char* path, int ticks) {
 	return 0;
 }
 
+// examples/02-joint_control_internal_otg/02-joint_control_internal_otg.cpp:118-179 call for call: one JointTask with
+// the acceleration-limited internal OTG, goal steps every "second", limits raised after "5 seconds"; the schedule of
+// cycles 1000 / 3000 of 4000, 5000 and 10000 is compressed to ticks/8, 3 ticks/8 of ticks/2, 5 ticks/8 and the last
+// period, where the example adds jerk limits — which this build refuses with the documented error (exit code 3 if
+// it did anything else). Prints, per period, the state read and the torques.
+static int example02(int B, const char* path, int ticks) {
+	std::ifstream f(path, std::ios::binary);
+	Batch q0(7 * (size_t)B), dq0(7 * (size_t)B, 0.0);
+	f.read((char*)q0.data(), q0.size() * sizeof(double));
+	auto robot = std::make_shared<BatchedRobotModel>(B);
+	robot->setQ(q0);
+	robot->setDq(dq0);
+	robot->updateModel();													 // :118
+	auto joint_task = std::make_shared<JointTask>(robot);					 // :123
+	joint_task->setGains(100, 20);											 // :125
+	Batch goal_position = joint_task->getGoalPosition();					 // :126
+	joint_task->enableInternalOtgAccelerationLimited(M_PI / 3, M_PI);		 // :129
+	BatchedSimulation sim(*joint_task, 0.001, 1);
+	Batch N_prec(49 * (size_t)B, 0.0);
+	const int period = ticks / 2;
+	for (int cycle = 0; cycle < ticks; cycle++) {
+		const Batch q = sim.getJointPositions(), dq = sim.getJointVelocities();
+		std::fwrite(q.data(), sizeof(double), q.size(), stdout);
+		std::fwrite(dq.data(), sizeof(double), dq.size(), stdout);
+		robot->setQ(q);	 // :141-143
+		robot->setDq(dq);
+		robot->updateModel();
+		for (int i = 0; i < 7; i++)
+			for (int b = 0; b < B; b++) N_prec[(size_t)(8 * i) * B + b] = 1.0;	 // :146
+		joint_task->updateTaskModel(N_prec);									 // :147
+		if (cycle % period == period / 4)										 // :151-155
+			for (int b = 0; b < B; b++) goal_position[(size_t)1 * B + b] -= 0.2, goal_position[(size_t)2 * B + b] += 0.4, goal_position[(size_t)3 * B + b] -= 0.6;
+		if (cycle % period == 3 * period / 4)									 // :156-160
+			for (int b = 0; b < B; b++) goal_position[(size_t)1 * B + b] += 0.2, goal_position[(size_t)2 * B + b] -= 0.4, goal_position[(size_t)3 * B + b] += 0.6;
+		joint_task->setGoalPosition(goal_position);								 // :161
+		if (cycle == 5 * ticks / 8) joint_task->enableInternalOtgAccelerationLimited(M_PI, 3 * M_PI);  // :164-169
+		if (cycle == ticks - 1) {												 // :171-176
+			try {
+				joint_task->enableInternalOtgJerkLimited(M_PI, 3 * M_PI, 3 * M_PI);
+				return 3;
+			} catch (const std::invalid_argument& e) {
+				if (!std::strstr(e.what(), "jerk-limited")) return 3;
+			}
+		}
+		const Batch joint_task_torques = joint_task->computeTorques();	// :178
+		std::fwrite(joint_task_torques.data(), sizeof(double), joint_task_torques.size(), stdout);
+		sim.setJointTorques(joint_task_torques);
+		sim.integrate();
+	}
+	return 0;
+}
+
 // examples/11-planar_robot_controller/11-planar_robot_controller.cpp:99-166 call for call: the planar 4R read from its
 // URDF, a partial MotionForceTask (x, y, rotation about z) on "link4" given by name and a JointTask behind it in a
 // RobotController, both with the reference's default internal OTG left on; the goal steps of cycles 0 / 2000 of
@@ -439,6 +492,7 @@ int main(int argc, char** argv) {
 		if (argc >= 6 && std::strcmp(argv[1], "example06") == 0) return example06(std::atoi(argv[2]), argv[3], argv[4], std::atoi(argv[5]));
 		if (argc >= 5 && std::strcmp(argv[1], "example04") == 0) return example04(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 6 && std::strcmp(argv[1], "example11") == 0) return example11(std::atoi(argv[2]), argv[3], argv[4], std::atoi(argv[5]));
+		if (argc >= 5 && std::strcmp(argv[1], "example02") == 0) return example02(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example18") == 0) return example18(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example01") == 0) return example01(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 2 && std::strcmp(argv[1], "validate") == 0) return validate();

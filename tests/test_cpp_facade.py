@@ -320,3 +320,51 @@ def test_cpp_example_11_planar_robot_controller(facade_bin, tmp_path):
         moved = max(moved, np.abs(q - q0).max())
     assert worst < 1e-9, worst
     assert moved > 0.1  # the generators carried the arm towards the stepped goal
+
+
+@pytest.mark.gpu
+def test_cpp_example_02_joint_control_internal_otg(facade_bin, tmp_path):
+    """tests/cpp/facade_test.cpp::example02 = examples/02-joint_control_internal_otg.cpp:118-179 call for call: a JointTask
+    following goal steps along acceleration-limited trajectories, limits raised in mid-run (re-planning of moving
+    generators); the example's last phase (jerk limits) is refused by this build, which the program checks."""
+    import oracle_lib as ol
+
+    B, ticks = 64, 640
+    inp = pkg.workloads.make_inputs(3, B=B, seed=202)
+    path = tmp_path / "q.bin"
+    inp["q"].astype(np.float64).tofile(path)
+    r = subprocess.run([facade_bin, "example02", str(B), str(path), str(ticks)], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    out = np.frombuffer(r.stdout, dtype=np.float64).reshape(ticks, 3, 7, B)
+    cfg = ol.joint_task("joint_task", internal_otg=True)
+    for i in range(7):
+        cfg.kp[i], cfg.kv[i], cfg.ki[i] = 100, 20, 0
+        cfg.otg_max_velocity[i], cfg.otg_max_acceleration[i] = np.pi / 3, np.pi
+    o = ol.Oracle(ol.panda_model(), [cfg], B, threads=8)
+    o.set_state(inp["q"], np.zeros_like(inp["q"]))
+    o.reinitialize()
+    goal = inp["q"].copy()
+    eye = np.repeat(np.eye(7).reshape(49, 1), B, axis=1)
+    period = ticks // 2
+    moved = 0.0
+    for cycle in range(ticks):
+        q, dq, tau_g = out[cycle]
+        o.set_state(q, dq)
+        o.task_update_model(0, eye)
+        if cycle % period == period // 4:
+            goal[1] -= 0.2
+            goal[2] += 0.4
+            goal[3] -= 0.6
+        if cycle % period == 3 * period // 4:
+            goal[1] += 0.2
+            goal[2] -= 0.4
+            goal[3] += 0.6
+        o.set_jt_goals(0, goal)
+        if cycle == 5 * ticks // 8:
+            for i in range(7):
+                cfg.otg_max_velocity[i], cfg.otg_max_acceleration[i] = np.pi, 3 * np.pi
+            o.update_task_config(0, cfg)
+        tau = o.task_compute_torques(0)
+        assert _err(tau_g, tau) < 1e-9, (cycle, _err(tau_g, tau))
+        moved = max(moved, np.abs(q - inp["q"]).max())
+    assert moved > 0.2  # the generators carried the joints towards the stepped goals
