@@ -5,6 +5,7 @@
 //   facade_test example04 <B> <in> <ticks> / example01 <B> <in> <ticks>   (GPU) the reference's examples 04 and 01,
 //                               tasks driven through the TemplateTask virtuals with no RobotController
 //   facade_test example02 <B> <in> <ticks>   (GPU) example 02: JointTask with the acceleration-limited internal OTG
+//   facade_test example03 <B> <in> <ticks>   (GPU) example 03: MotionForceTask with the Cartesian internal OTG
 //   facade_test example18 <B> <in> <ticks>   (GPU) example 18: the Panda driven into its singularities
 //   facade_test example11 <B> <urdf> <in> <ticks>   (GPU) example 11: the planar 4R from its URDF, RobotController
 //   facade_test example06 <B> <urdf> <in> <ticks>   (GPU) example 06: the 8-joint sliding-base Panda from its URDF
@@ -430,6 +431,73 @@ static int example02(int B, const char* path, int ticks) {
 	return 0;
 }
 
+// examples/03-cartesian_motion_control/03-cartesian_motion_control.cpp:109-183 call for call: one MotionForceTask with the
+// reference's default (acceleration-limited, Cartesian) internal OTG, goal steps of 0.1 m in z with a 45 degree turn
+// about z, the generator switched off later on; cycles 500 / 2000 of 3000, 6500 and 12500 are compressed to P/6 and
+// 2P/3 of P = ticks/2, 13 ticks/18 and the last period, where the example asks for jerk limits (refused by this
+// build; exit code 3 otherwise). Prints, per period, the state read and the torques.
+static int example03(int B, const char* path, int ticks) {
+	std::ifstream f(path, std::ios::binary);
+	Batch q0(7 * (size_t)B), dq0(7 * (size_t)B, 0.0);
+	f.read((char*)q0.data(), q0.size() * sizeof(double));
+	auto robot = std::make_shared<BatchedRobotModel>(B);
+	robot->setQ(q0);
+	robot->setDq(dq0);
+	robot->updateModel();										// :112
+	const double pos_in_link[3] = {0.07, 0.0, 0.15};			// "end-effector" (0.07, 0, 0) seen from link7 (:117-122)
+	auto motion_force_task = std::make_unique<MotionForceTask>(robot, 6, pos_in_link);	// :123-125
+	motion_force_task->setPosControlGains(100.0, 20.0);		// :128-129
+	motion_force_task->setOriControlGains(100.0, 20.0);
+	Batch goal_orientation = motion_force_task->getCurrentOrientation();  // :132-135
+	Batch goal_position = motion_force_task->getCurrentPosition();
+	BatchedSimulation sim(*motion_force_task, 0.001, 1);
+	const double th = M_PI / 4.0, R[9] = {std::cos(th), std::sin(th), 0, -std::sin(th), std::cos(th), 0, 0, 0, 1};	// :156-158
+	const int period = ticks / 2;
+	auto turn = [&](bool transpose) {  // goal_orientation = R (or R^T) * goal_orientation
+		Batch out(goal_orientation.size());
+		for (int b = 0; b < B; b++)
+			for (int i = 0; i < 3; i++)
+				for (int j = 0; j < 3; j++) {
+					double v = 0;
+					for (int k = 0; k < 3; k++) v += (transpose ? R[3 * k + i] : R[3 * i + k]) * goal_orientation[(size_t)(3 * k + j) * B + b];
+					out[(size_t)(3 * i + j) * B + b] = v;
+				}
+		goal_orientation = out;
+	};
+	for (int cycle = 0; cycle < ticks; cycle++) {
+		const Batch q = sim.getJointPositions(), dq = sim.getJointVelocities();
+		std::fwrite(q.data(), sizeof(double), q.size(), stdout);
+		std::fwrite(dq.data(), sizeof(double), dq.size(), stdout);
+		robot->setQ(q);	 // :146-148
+		robot->setDq(dq);
+		robot->updateModel();
+		motion_force_task->updateTaskModel();  // :151-152 N_prec = identity
+		if (cycle % period == 2 * period / 3) {	 // :159-162
+			for (int b = 0; b < B; b++) goal_position[(size_t)2 * B + b] += 0.1;
+			turn(false);
+		} else if (cycle % period == period / 6) {	// :164-167
+			for (int b = 0; b < B; b++) goal_position[(size_t)2 * B + b] -= 0.1;
+			turn(true);
+		}
+		motion_force_task->setGoalPosition(goal_position);		 // :168-169
+		motion_force_task->setGoalOrientation(goal_orientation);
+		if (cycle == 13 * ticks / 18) motion_force_task->disableInternalOtg();	// :172-174
+		if (cycle == ticks - 1) {												// :177-180
+			try {
+				motion_force_task->enableInternalOtgJerkLimited(0.3, 1.0, 3.0, M_PI / 3, M_PI, 3 * M_PI);
+				return 3;
+			} catch (const std::invalid_argument& e) {
+				if (!std::strstr(e.what(), "jerk-limited")) return 3;
+			}
+		}
+		const Batch motion_force_task_torques = motion_force_task->computeTorques();  // :182-183
+		std::fwrite(motion_force_task_torques.data(), sizeof(double), motion_force_task_torques.size(), stdout);
+		sim.setJointTorques(motion_force_task_torques);
+		sim.integrate();
+	}
+	return 0;
+}
+
 // examples/11-planar_robot_controller/11-planar_robot_controller.cpp:99-166 call for call: the planar 4R read from its
 // URDF, a partial MotionForceTask (x, y, rotation about z) on "link4" given by name and a JointTask behind it in a
 // RobotController, both with the reference's default internal OTG left on; the goal steps of cycles 0 / 2000 of
@@ -493,6 +561,7 @@ int main(int argc, char** argv) {
 		if (argc >= 5 && std::strcmp(argv[1], "example04") == 0) return example04(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 6 && std::strcmp(argv[1], "example11") == 0) return example11(std::atoi(argv[2]), argv[3], argv[4], std::atoi(argv[5]));
 		if (argc >= 5 && std::strcmp(argv[1], "example02") == 0) return example02(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
+		if (argc >= 5 && std::strcmp(argv[1], "example03") == 0) return example03(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example18") == 0) return example18(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example01") == 0) return example01(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 2 && std::strcmp(argv[1], "validate") == 0) return validate();

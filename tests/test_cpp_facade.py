@@ -368,3 +368,55 @@ def test_cpp_example_02_joint_control_internal_otg(facade_bin, tmp_path):
         assert _err(tau_g, tau) < 1e-9, (cycle, _err(tau_g, tau))
         moved = max(moved, np.abs(q - inp["q"]).max())
     assert moved > 0.2  # the generators carried the joints towards the stepped goals
+
+
+@pytest.mark.gpu
+def test_cpp_example_03_cartesian_motion_control(facade_bin, tmp_path):
+    """tests/cpp/facade_test.cpp::example03 = examples/03-cartesian_motion_control.cpp:109-183 call for call: a
+    MotionForceTask following position + orientation goal steps along the Cartesian generator's trajectories
+    (new goals while still moving), the generator switched off in mid-run; the example's last phase (jerk limits) is
+    refused by this build, which the program checks."""
+    import oracle_lib as ol
+
+    B, ticks = 64, 900
+    inp = pkg.workloads.make_inputs(3, B=B, seed=303)
+    path = tmp_path / "q.bin"
+    inp["q"].astype(np.float64).tofile(path)
+    r = subprocess.run([facade_bin, "example03", str(B), str(path), str(ticks)], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    out = np.frombuffer(r.stdout, dtype=np.float64).reshape(ticks, 3, 7, B)
+    cfg = ol.motion_force_task("motion_force_task", frame_pos=(0.07, 0.0, 0.15), internal_otg=True)
+    for i in range(3):
+        cfg.kp_pos[i], cfg.kv_pos[i], cfg.ki_pos[i] = 100.0, 20.0, 0.0
+        cfg.kp_ori[i], cfg.kv_ori[i], cfg.ki_ori[i] = 100.0, 20.0, 0.0
+    o = ol.Oracle(ol.panda_model(), [cfg], B, threads=8)
+    o.set_state(inp["q"], np.zeros_like(inp["q"]))
+    o.reinitialize()
+    st = o.get_mft_status(0)
+    gp, gR = st["pos"].copy(), st["rot"].reshape(3, 3, B).copy()
+    th = np.pi / 4
+    R = np.array([[np.cos(th), np.sin(th), 0], [-np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    period = ticks // 2
+    worst_regular, moved = 0.0, 0.0
+    for cycle in range(ticks):
+        q, dq, tau_g = out[cycle]
+        o.set_state(q, dq)
+        o.task_update_model(0, None)
+        if cycle % period == 2 * period // 3:
+            gp[2] += 0.1
+            gR = np.einsum("ik,kjb->ijb", R, gR)
+        elif cycle % period == period // 6:
+            gp[2] -= 0.1
+            gR = np.einsum("ki,kjb->ijb", R, gR)
+        o.set_mft_goals(0, gp, np.ascontiguousarray(gR.reshape(9, B)), None, None, None, None)
+        if cycle == 13 * ticks // 18:
+            cfg.use_internal_otg = 0
+            o.update_task_config(0, cfg)
+        tau = o.task_compute_torques(0)
+        _, _, ro = o.get_mft_singularity(0)
+        e = np.abs(tau_g - tau).max(axis=0) / np.maximum(np.abs(tau).max(axis=0), 1)
+        assert e.max() < 1e-5, (cycle, e.max())
+        worst_regular = max(worst_regular, e[ro == 6].max(initial=0.0))
+        moved = max(moved, np.abs(q - inp["q"]).max())
+    assert worst_regular < 1e-9, worst_regular
+    assert moved > 0.1
