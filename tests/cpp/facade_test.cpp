@@ -6,6 +6,7 @@
 //                               tasks driven through the TemplateTask virtuals with no RobotController
 //   facade_test example02 <B> <in> <ticks>   (GPU) example 02: JointTask with the acceleration-limited internal OTG
 //   facade_test example03 <B> <in> <ticks>   (GPU) example 03: MotionForceTask with the Cartesian internal OTG
+//   facade_test example09 <B> <in> <ticks>   (GPU) example 09: position control until contact, then force control with POPC
 //   facade_test example18 <B> <in> <ticks>   (GPU) example 18: the Panda driven into its singularities
 //   facade_test example11 <B> <urdf> <in> <ticks>   (GPU) example 11: the planar 4R from its URDF, RobotController
 //   facade_test example06 <B> <urdf> <in> <ticks>   (GPU) example 06: the 8-joint sliding-base Panda from its URDF
@@ -498,6 +499,84 @@ static int example03(int B, const char* path, int ticks) {
 	return 0;
 }
 
+// examples/09-3d_position_force_controller/09-3d_position_force_controller.cpp:106-206 call for call on the Panda: a
+// translation-only MotionForceTask + JointTask in a RobotController, the goal moving in x / y and sinking in z until
+// the force sensor reports contact, then force control along z (goal -5 N, closed loop, passivity observer on). Two
+// things differ from the example and are part of what a batch means: (1) the contact is a virtual spring under each
+// robot's start height (2 kN/m, sensed in the control frame; the simulation here has no contact), (2) a task's
+// configuration is one per controller, so the switch to force control happens when EVERY robot reports contact.
+// Cycle numbers 1000 / 2000 / 3000 are compressed to ticks/6, ticks/3, ticks/2. Prints, per period: q, dq, the
+// sensor reading handed to the task (3 rows), the force-control flag (1 row) and the torques.
+static int example09(int B, const char* path, int ticks) {
+	std::ifstream f(path, std::ios::binary);
+	Batch q0(7 * (size_t)B), dq0(7 * (size_t)B, 0.0);
+	f.read((char*)q0.data(), q0.size() * sizeof(double));
+	auto robot = std::make_shared<BatchedRobotModel>(B);
+	robot->setQ(q0);
+	robot->setDq(dq0);
+	robot->updateModel();  // :109
+	const double pos_in_link[3] = {0.0, 0.0, 0.15};
+	const std::vector<double> controlled_directions_translation = {1, 0, 0, 0, 1, 0, 0, 0, 1};	// :113-116
+	const std::vector<double> controlled_directions_rotation = {};								// :117
+	auto motion_force_task = std::make_shared<MotionForceTask>(robot, 6, controlled_directions_translation, controlled_directions_rotation,
+																pos_in_link);  // :118-120
+	bool force_control = false;													   // :121
+	const Batch initial_position = motion_force_task->getCurrentPosition();		   // :124
+	Batch goal_position = initial_position;
+	auto joint_task = std::make_shared<JointTask>(robot);										   // :128
+	std::vector<std::shared_ptr<TemplateTask>> task_list = {motion_force_task, joint_task};	   // :131-132
+	auto robot_controller = std::make_unique<RobotController>(robot, task_list);				   // :133-134
+	BatchedSimulation sim(*robot_controller, 0.001, 1);
+	const int k2000 = ticks / 3, k1000 = ticks / 6, k3000 = ticks / 2;
+	for (int cycle = 0; cycle < ticks; cycle++) {
+		const Batch q = sim.getJointPositions(), dq = sim.getJointVelocities();
+		std::fwrite(q.data(), sizeof(double), q.size(), stdout);
+		std::fwrite(dq.data(), sizeof(double), dq.size(), stdout);
+		robot->setQ(q);	 // :144-146
+		robot->setDq(dq);
+		robot->updateModel();
+		robot_controller->updateControllerTaskModels();	 // :149
+		// the force sensor: a spring 4 mm under the start height, read in the control frame
+		const Batch x = motion_force_task->getCurrentPosition(), R = motion_force_task->getCurrentOrientation();
+		Batch sensed_force(3 * (size_t)B), zero(3 * (size_t)B, 0.0);
+		for (int b = 0; b < B; b++) {
+			const double pen = (initial_position[(size_t)2 * B + b] - 0.004) - x[(size_t)2 * B + b];
+			const double fz = pen > 0 ? -2000.0 * pen : 0.0;
+			for (int i = 0; i < 3; i++) sensed_force[(size_t)i * B + b] = R[(size_t)(6 + i) * B + b] * fz;	 // R^T (0, 0, fz)
+		}
+		motion_force_task->updateSensedForceAndMoment(sensed_force, zero);	// :152-156
+		std::fwrite(sensed_force.data(), sizeof(double), sensed_force.size(), stdout);
+		if (cycle % k2000 == 0)	 // :162-168
+			for (int b = 0; b < B; b++) goal_position[b] -= 0.07, goal_position[(size_t)B + b] -= 0.07;
+		else if (cycle % k2000 == k1000)
+			for (int b = 0; b < B; b++) goal_position[b] += 0.07, goal_position[(size_t)B + b] += 0.07;
+		if (cycle > k2000 && cycle < k3000)	 // :169-171
+			for (int b = 0; b < B; b++) goal_position[(size_t)2 * B + b] -= 0.00015;
+		motion_force_task->setGoalPosition(goal_position);	// :172
+		if (!force_control) {								// :174-183
+			const Batch fw = motion_force_task->getSensedForceControlWorldFrame();
+			bool all = true;
+			for (int b = 0; b < B; b++) all = all && fw[(size_t)2 * B + b] <= -1.0;
+			if (all) {
+				force_control = true;
+				const double unit_z[3] = {0, 0, 1};
+				motion_force_task->parametrizeForceMotionSpaces(1, unit_z);
+				Batch gf(3 * (size_t)B, 0.0);
+				for (int b = 0; b < B; b++) gf[(size_t)2 * B + b] = -5.0;
+				motion_force_task->setGoalForce(gf);
+				motion_force_task->setClosedLoopForceControl();
+				motion_force_task->enablePassivity();
+			}
+		}
+		const Batch flag((size_t)B, force_control ? 1.0 : 0.0);
+		std::fwrite(flag.data(), sizeof(double), flag.size(), stdout);
+		const Batch control_torques = robot_controller->computeControlTorques();  // :201-204
+		std::fwrite(control_torques.data(), sizeof(double), control_torques.size(), stdout);
+		sim.integrate();
+	}
+	return force_control ? 0 : 4;  // the scenario must have reached the force-control phase
+}
+
 // examples/11-planar_robot_controller/11-planar_robot_controller.cpp:99-166 call for call: the planar 4R read from its
 // URDF, a partial MotionForceTask (x, y, rotation about z) on "link4" given by name and a JointTask behind it in a
 // RobotController, both with the reference's default internal OTG left on; the goal steps of cycles 0 / 2000 of
@@ -562,6 +641,7 @@ int main(int argc, char** argv) {
 		if (argc >= 6 && std::strcmp(argv[1], "example11") == 0) return example11(std::atoi(argv[2]), argv[3], argv[4], std::atoi(argv[5]));
 		if (argc >= 5 && std::strcmp(argv[1], "example02") == 0) return example02(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example03") == 0) return example03(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
+		if (argc >= 5 && std::strcmp(argv[1], "example09") == 0) return example09(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example18") == 0) return example18(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example01") == 0) return example01(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 2 && std::strcmp(argv[1], "validate") == 0) return validate();

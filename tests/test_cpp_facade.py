@@ -420,3 +420,63 @@ def test_cpp_example_03_cartesian_motion_control(facade_bin, tmp_path):
         moved = max(moved, np.abs(q - inp["q"]).max())
     assert worst_regular < 1e-9, worst_regular
     assert moved > 0.1
+
+
+@pytest.mark.gpu
+def test_cpp_example_09_position_then_force_control(facade_bin, tmp_path):
+    """tests/cpp/facade_test.cpp::example09 = examples/09-3d_position_force_controller.cpp:106-206 call for call (on the
+    Panda, contact = a virtual spring, the switch to force control when every robot of the batch reports contact: a
+    task's configuration is one per controller): updateSensedForceAndMoment every period, then
+    parametrizeForceMotionSpaces / setGoalForce / setClosedLoopForceControl / enablePassivity in mid-run."""
+    import oracle_lib as ol
+
+    B, ticks = 32, 720
+    inp = pkg.workloads.make_inputs(3, B=B, seed=909)
+    path = tmp_path / "q.bin"
+    inp["q"].astype(np.float64).tofile(path)
+    r = subprocess.run([facade_bin, "example09", str(B), str(path), str(ticks)], capture_output=True)
+    assert r.returncode == 0, (r.returncode, r.stderr.decode())
+    out = np.frombuffer(r.stdout, dtype=np.float64).reshape(ticks, 25, B)
+    partial = (np.eye(3), np.zeros((0, 3)))
+    mcfg = ol.motion_force_task("partial_motion_force_task", frame_pos=(0.0, 0.0, 0.15), partial=partial, internal_otg=True)
+    jcfg = ol.joint_task("joint_task", internal_otg=True)
+    o = ol.Oracle(ol.panda_model(), [mcfg, jcfg], B, threads=8)
+    o.set_state(inp["q"], np.zeros_like(inp["q"]))
+    o.reinitialize()
+    goal = o.get_mft_status(0)["pos"].copy()
+    k2000, k1000, k3000 = ticks // 3, ticks // 6, ticks // 2
+    force_control, switched_at = False, None
+    worst_regular = 0.0
+    for cycle in range(ticks):
+        q, dq, sensed, flag, tau_g = out[cycle, :7], out[cycle, 7:14], out[cycle, 14:17], out[cycle, 17], out[cycle, 18:]
+        o.set_state(q, dq)
+        o.update_task_models()
+        o.set_mft_sensed_wrench(0, np.ascontiguousarray(sensed), np.zeros((3, B)))
+        if cycle % k2000 == 0:
+            goal[0] -= 0.07
+            goal[1] -= 0.07
+        elif cycle % k2000 == k1000:
+            goal[0] += 0.07
+            goal[1] += 0.07
+        if k2000 < cycle < k3000:
+            goal[2] -= 0.00015
+        o.set_mft_goals(0, goal, None, None, None, None, None)
+        if not force_control and flag[0] == 1.0:
+            force_control, switched_at = True, cycle
+            mcfg.force_space_dimension = 1
+            mcfg.force_axis[0], mcfg.force_axis[1], mcfg.force_axis[2] = 0.0, 0.0, 1.0
+            o.update_task_config(0, mcfg)
+            gf = np.zeros((3, B))
+            gf[2] = -5.0
+            o.set_mft_goal_wrench(0, gf, np.zeros((3, B)))
+            mcfg.closed_loop_force = 1
+            o.update_task_config(0, mcfg)
+            mcfg.passivity_enabled = 1
+            o.update_task_config(0, mcfg)
+        tau = o.compute_control_torques(True)
+        _, _, ro = o.get_mft_singularity(0)
+        e = np.abs(tau_g - tau).max(axis=0) / np.maximum(np.abs(tau).max(axis=0), 1)
+        assert e.max() < 1e-5, (cycle, e.max())
+        worst_regular = max(worst_regular, e[ro == 3].max(initial=0.0))
+    assert switched_at is not None and k2000 < switched_at < ticks - 50, switched_at  # contact, then a stretch of force control
+    assert worst_regular < 1e-9, worst_regular
