@@ -608,6 +608,28 @@ public:
 		for (int i = 0; i < 9; i++) _cfg.sensor_rot[i] = sensor_rot_in_control_frame ? sensor_rot_in_control_frame[i] : (i % 4 == 0 ? 1.0 : 0.0);
 		syncConfig();
 	}
+	// MotionForceTask::setForceSensorFrame(link_name, transformation_in_link) (MotionForceTask.cpp:794-803): the sensor
+	// frame given in the link, _T_control_to_sensor = compliant_frame^-1 * transformation_in_link; the sensor must sit
+	// on the control frame's link (for a link NAME: on a link rigidly attached to the same moving link)
+	void setForceSensorFrame(const int link, const double sensor_pos_in_link[3], const double* sensor_rot_in_link) {
+		if (link != _cfg.link)
+			throw std::invalid_argument("The link to which is attached the sensor should be the same as the link to which is attached the control frame in MotionForceTask::setForceSensorFrame\n");
+		const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+		const double* Rs = sensor_rot_in_link ? sensor_rot_in_link : I9;
+		const double* Rc = _cfg.frame_rot;
+		double d[3], p[3], R[9];
+		for (int i = 0; i < 3; i++) d[i] = sensor_pos_in_link[i] - _cfg.frame_pos[i];
+		for (int i = 0; i < 3; i++) {
+			p[i] = Rc[i] * d[0] + Rc[3 + i] * d[1] + Rc[6 + i] * d[2];	 // Rc^T (ps - pc)
+			for (int j = 0; j < 3; j++) R[3 * i + j] = Rc[i] * Rs[j] + Rc[3 + i] * Rs[3 + j] + Rc[6 + i] * Rs[6 + j];  // Rc^T Rs
+		}
+		setForceSensorFrame(p, R);
+	}
+	void setForceSensorFrame(const std::string& link_name, const double sensor_pos_in_link[3], const double* sensor_rot_in_link = nullptr) {
+		double fp[3], fr[9];
+		const int link = _robot->resolveLink(link_name, sensor_pos_in_link, sensor_rot_in_link, fp, fr);
+		setForceSensorFrame(link, fp, fr);
+	}
 	int getForceSpaceDimension() const { return _cfg.force_space_dimension; }
 	int getMomentSpaceDimension() const { return _cfg.moment_space_dimension; }
 	bool getVelocitySaturationEnabled() const { return _cfg.use_velocity_saturation != 0; }

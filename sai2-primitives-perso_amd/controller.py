@@ -1054,8 +1054,25 @@ class MotionForceTask(_TaskBase):
     def getMaxMomentControlFeedbackOutput(self):
         return self._cfg.max_moment_feedback
 
-    def setForceSensorFrame(self, sensor_pos_in_control_frame, sensor_rot_in_control_frame=None):
-        """_T_control_to_sensor (MotionForceTask.cpp:794-803), given directly in the control frame"""
+    def setForceSensorFrame(self, *args):
+        """MotionForceTask::setForceSensorFrame (MotionForceTask.cpp:794-803). Two forms:
+        (link, sensor_pos_in_link, sensor_rot_in_link=None) — the reference's: link index or NAME, the sensor frame in
+        that link, which must be the control frame's; _T_control_to_sensor = compliant_frame^-1 * transformation_in_link;
+        (sensor_pos_in_control_frame, sensor_rot_in_control_frame=None) — _T_control_to_sensor given directly."""
+        if isinstance(args[0], (int, np.integer, str)):
+            link, ps = args[0], np.asarray(args[1], dtype=float)
+            Rs = np.eye(3) if len(args) < 3 or args[2] is None else np.asarray(args[2], dtype=float).reshape(3, 3)
+            if isinstance(link, str):
+                if self._robot.links is None:
+                    raise ValueError("link names need a robot model built from a URDF file")
+                link, ps, Rs = resolve_link_frame(self._robot.links, link, ps, Rs)
+            if int(link) != self._cfg.link:
+                raise ValueError("The link to which is attached the sensor should be the same as the link to which is attached "
+                                 "the control frame in MotionForceTask::setForceSensorFrame\n")
+            Rc, pc = np.array(self._cfg.frame_rot[:]).reshape(3, 3), np.array(self._cfg.frame_pos[:])
+            return self.setForceSensorFrame(Rc.T @ (np.asarray(ps) - pc), Rc.T @ Rs)
+        sensor_pos_in_control_frame = args[0]
+        sensor_rot_in_control_frame = args[1] if len(args) > 1 else None
         p = np.asarray(sensor_pos_in_control_frame, dtype=float)
         R = np.eye(3) if sensor_rot_in_control_frame is None else np.asarray(sensor_rot_in_control_frame, dtype=float)
         for i in range(3):

@@ -96,6 +96,20 @@ static int validate() {
 		MotionForceTask m(robot, 6, std::vector<double>{1, 0, 0, 0, 1, 0}, std::vector<double>{0, 0, 1}, pos);
 		const std::vector<double> pp = m.posSelectionProjector(), po = m.oriSelectionProjector();
 		expect(pp[0] == 1 && pp[4] == 1 && pp[8] == 0 && po[8] == 1 && po[0] == 0, "selection projectors of a partial task");
+		{	// sensor frame given in the link (MotionForceTask.cpp:794-803): T_control_to_sensor = compliant_frame^-1 * T
+			const double c = std::cos(0.3), sn = std::sin(0.3);
+			const double frot[9] = {c, -sn, 0, sn, c, 0, 0, 0, 1}, fpos[3] = {0.01, 0.02, 0.2};
+			MotionForceTask ms(robot, 6, fpos, frot);
+			const double spos[3] = {0.03, -0.01, 0.25};
+			ms.setForceSensorFrame(6, spos, nullptr);
+			const sai2b_task_config& k = ms.config();
+			const double d[3] = {0.02, -0.03, 0.05};
+			bool ok = std::fabs(k.sensor_pos[0] - (c * d[0] + sn * d[1])) < 1e-15 && std::fabs(k.sensor_pos[1] - (-sn * d[0] + c * d[1])) < 1e-15 &&
+					  std::fabs(k.sensor_pos[2] - d[2]) < 1e-15 && std::fabs(k.sensor_rot[0] - c) < 1e-15 && std::fabs(k.sensor_rot[1] - sn) < 1e-15 &&
+					  std::fabs(k.sensor_rot[3] + sn) < 1e-15;
+			expect(ok, "sensor frame relative to the control frame");
+			expect(throws_invalid([&] { ms.setForceSensorFrame(5, spos, nullptr); }, "same as the link"), "sensor on another link");
+		}
 		m.enableVelocitySaturation(0.25, 0.5);
 		expect(m.getLinearSaturationVelocity() == 0.25 && m.getAngularSaturationVelocity() == 0.5, "saturation velocities");
 	}

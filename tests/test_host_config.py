@@ -149,3 +149,17 @@ def test_facades_carry_every_public_member_name_of_the_reference_headers():
                 if not re.search(r"\b" + name + r"\b", text):
                     missing.append((h, name, where))
     assert not missing, missing
+
+
+def test_python_facade_sensor_frame_given_in_the_link():
+    """MotionForceTask::setForceSensorFrame(link, transformation_in_link) (MotionForceTask.cpp:794-803):
+    _T_control_to_sensor = compliant_frame^-1 * transformation_in_link, same link required (no device needed)"""
+    robot = pkg.BatchedRobotModel(4)
+    c, s = np.cos(0.3), np.sin(0.3)
+    frot = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+    m = pkg.MotionForceTask(robot, 6, (0.01, 0.02, 0.2), frot)
+    m.setForceSensorFrame(6, (0.03, -0.01, 0.25))
+    assert np.allclose(np.array(m._cfg.sensor_pos[:]), frot.T @ np.array([0.02, -0.03, 0.05]), atol=1e-16)
+    assert np.allclose(np.array(m._cfg.sensor_rot[:]).reshape(3, 3), frot.T, atol=1e-16)
+    with pytest.raises(ValueError, match="same as the link"):
+        m.setForceSensorFrame(5, (0, 0, 0))
