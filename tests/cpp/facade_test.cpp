@@ -8,6 +8,7 @@
 //   facade_test example03 <B> <in> <ticks>   (GPU) example 03: MotionForceTask with the Cartesian internal OTG
 //   facade_test example09 <B> <in> <ticks>   (GPU) example 09: position control until contact, then force control with POPC
 //   facade_test example18 <B> <in> <ticks>   (GPU) example 18: the Panda driven into its singularities
+//   facade_test example19 <B> <urdf> <in> <ticks>   (GPU) example 19: a 6R arm started in its wrist singularity
 //   facade_test example11 <B> <urdf> <in> <ticks>   (GPU) example 11: the planar 4R from its URDF, RobotController
 //   facade_test example06 <B> <urdf> <in> <ticks>   (GPU) example 06: the 8-joint sliding-base Panda from its URDF
 #include <cmath>
@@ -648,10 +649,88 @@ static int example11(int B, const char* urdf, const char* path, int ticks) {
 	return 0;
 }
 
+// examples/19-puma_singularity/19-puma_singularity.cpp:129-270 call for call (the wrist-lock variant) on a 6R arm read
+// from a URDF (tests/robots.py: six_r, PUMA-like; the PUMA's own URDF is not part of the reference tree): a 6-DOF
+// MotionForceTask (internal OTG on, singularity handling gains 50 / 20 / 20) started IN the wrist singularity and a
+// JointTask behind it, nullspaces chained by hand; the state machine sends the frame 0.2 m down with a 90 degree turn
+// about its z and back, every "5 seconds" = ticks/6 periods. Prints, per period, the state read and the torques.
+static int example19(int B, const char* urdf, const char* path, int ticks) {
+	auto robot = std::make_shared<BatchedRobotModel>(std::string(urdf), B);
+	const int dof = robot->dof();
+	std::ifstream f(path, std::ios::binary);
+	Batch q0((size_t)dof * B), dq0((size_t)dof * B, 0.0);
+	f.read((char*)q0.data(), q0.size() * sizeof(double));
+	f.read((char*)dq0.data(), dq0.size() * sizeof(double));
+	robot->setQ(q0);
+	robot->setDq(dq0);
+	robot->updateModel();  // :132
+	const double pos_in_link[3] = {0.0, 0.0, 0.0};	// :139-140
+	auto motion_force_task = std::make_unique<MotionForceTask>(robot, std::string("link6"), pos_in_link);  // :143-144
+	motion_force_task->setSingularityHandlingGains(50, 20, 20);										   // :145
+	auto joint_task = std::make_unique<JointTask>(robot);												   // :178
+	joint_task->setGains(100, 20);																		   // :179
+	const Batch initial_q = robot->q();																	   // :182
+	joint_task->setGoalPosition(initial_q);																   // :183
+	enum { GO_TO_SINGULARITY, EXIT_SINGULARITY } state = GO_TO_SINGULARITY;								   // :185
+	int start = 0, cnt = 0;
+	const int five_seconds = ticks / 6;
+	Batch starting_ee_pos, starting_ee_ori;
+	BatchedSimulation sim(*motion_force_task, 0.001, 1);
+	auto away = [&]() {	 // starting pose + (0, 0, -0.2), turned by 90 degrees about its own z (:214-217)
+		Batch p = starting_ee_pos, R(starting_ee_ori.size());
+		for (int b = 0; b < B; b++) {
+			p[(size_t)2 * B + b] -= 0.2;
+			for (int i = 0; i < 3; i++) {  // R * Rz(90): columns (y, -x, z) of R
+				R[(size_t)(3 * i + 0) * B + b] = starting_ee_ori[(size_t)(3 * i + 1) * B + b];
+				R[(size_t)(3 * i + 1) * B + b] = -starting_ee_ori[(size_t)(3 * i + 0) * B + b];
+				R[(size_t)(3 * i + 2) * B + b] = starting_ee_ori[(size_t)(3 * i + 2) * B + b];
+			}
+		}
+		motion_force_task->setGoalPosition(p);
+		motion_force_task->setGoalOrientation(R);
+	};
+	for (int cycle = 0; cycle < ticks; cycle++) {
+		const Batch q = sim.getJointPositions(), dq = sim.getJointVelocities();
+		std::fwrite(q.data(), sizeof(double), q.size(), stdout);
+		std::fwrite(dq.data(), sizeof(double), dq.size(), stdout);
+		robot->setQ(q);	 // :199-201
+		robot->setDq(dq);
+		robot->updateModel();
+		if (cycle - start > five_seconds && state == GO_TO_SINGULARITY) {  // :209-221
+			starting_ee_pos = motion_force_task->getCurrentPosition();	   // (robot->position / rotation of the frame, :204-206)
+			starting_ee_ori = motion_force_task->getCurrentOrientation();
+			away();
+			state = EXIT_SINGULARITY;
+			start = cycle;
+		}
+		if (cycle - start > five_seconds && state == EXIT_SINGULARITY) {  // :223-244
+			if (cnt == 0 || cnt == 2) {
+				motion_force_task->setGoalPosition(starting_ee_pos);
+				motion_force_task->setGoalOrientation(starting_ee_ori);
+			} else {
+				away();
+			}
+			start = cycle;
+			cnt = (cnt + 1) % 4;
+		}
+		motion_force_task->updateTaskModel();									// :250-255 N_prec = identity
+		const Batch N_prec = motion_force_task->getTaskAndPreviousNullspace();	// :256
+		joint_task->updateTaskModel(N_prec);									// :261
+		const Batch motion_force_task_torques = motion_force_task->computeTorques();  // :264
+		const Batch joint_task_torques = joint_task->computeTorques();				   // :265
+		const Batch control_torques = add(motion_force_task_torques, joint_task_torques);  // :270
+		std::fwrite(control_torques.data(), sizeof(double), control_torques.size(), stdout);
+		sim.setJointTorques(control_torques);
+		sim.integrate();
+	}
+	return 0;
+}
+
 int main(int argc, char** argv) {
 	try {
 		if (argc >= 6 && std::strcmp(argv[1], "example06") == 0) return example06(std::atoi(argv[2]), argv[3], argv[4], std::atoi(argv[5]));
 		if (argc >= 5 && std::strcmp(argv[1], "example04") == 0) return example04(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
+		if (argc >= 6 && std::strcmp(argv[1], "example19") == 0) return example19(std::atoi(argv[2]), argv[3], argv[4], std::atoi(argv[5]));
 		if (argc >= 6 && std::strcmp(argv[1], "example11") == 0) return example11(std::atoi(argv[2]), argv[3], argv[4], std::atoi(argv[5]));
 		if (argc >= 5 && std::strcmp(argv[1], "example02") == 0) return example02(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example03") == 0) return example03(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
