@@ -6,6 +6,7 @@
 //                               tasks driven through the TemplateTask virtuals with no RobotController
 //   facade_test example02 <B> <in> <ticks>   (GPU) example 02: JointTask with the acceleration-limited internal OTG
 //   facade_test example03 <B> <in> <ticks>   (GPU) example 03: MotionForceTask with the Cartesian internal OTG
+//   facade_test example07 <B> <in> <ticks>   (GPU) example 07: surface alignment, force + moment control in the compliant frame
 //   facade_test example09 <B> <in> <ticks>   (GPU) example 09: position control until contact, then force control with POPC
 //   facade_test example18 <B> <in> <ticks>   (GPU) example 18: the Panda driven into its singularities
 //   facade_test example19 <B> <urdf> <in> <ticks>   (GPU) example 19: a 6R arm started in its wrist singularity
@@ -592,6 +593,88 @@ static int example09(int B, const char* path, int ticks) {
 	return force_control ? 0 : 4;  // the scenario must have reached the force-control phase
 }
 
+// examples/07-surface_surface_contact/07-surface_surface_contact.cpp:124-228 call for call on the Panda: one 6-DOF
+// MotionForceTask parametrised in its COMPLIANT frame, passivity observer on, force sensor at the link origin
+// (setForceSensorFrame(link, identity)), sinking until contact, then force control along the frame's z and moment
+// control about its x and y (closed loop both, gains 0.7 / 5 / 1.5 and 0.7 / 4 / 1.5). As in example09 the contact
+// is virtual (a stiff spring 0.5 mm under the start height plus a torsional spring that wants the frame's z vertical,
+// read in the sensor frame) and the switch happens when every robot reports contact. Prints, per period: q, dq, the
+// sensor readings (force 3, moment 3), the contact-control flag (1 row) and the torques.
+static int example07(int B, const char* path, int ticks) {
+	std::ifstream f(path, std::ios::binary);
+	Batch q0(7 * (size_t)B), dq0(7 * (size_t)B, 0.0);
+	f.read((char*)q0.data(), q0.size() * sizeof(double));
+	auto robot = std::make_shared<BatchedRobotModel>(B);
+	robot->setQ(q0);
+	robot->setDq(dq0);
+	robot->updateModel();  // :130
+	const double pos_in_link[3] = {0.0, 0.0, 0.22};
+	auto motion_force_task = std::make_shared<MotionForceTask>(robot, 6, pos_in_link, nullptr, "surface_alignment_task", true);  // :134-136
+	motion_force_task->enablePassivity();		// :137
+	motion_force_task->disableInternalOtg();	// :138
+	const double origin[3] = {0, 0, 0};
+	motion_force_task->setForceSensorFrame(6, origin, nullptr);	 // :141
+	const Batch initial_position = motion_force_task->getCurrentPosition();	 // :145
+	Batch goal_position = initial_position;
+	std::vector<std::shared_ptr<TemplateTask>> task_list = {motion_force_task};		 // :150-151
+	auto robot_controller = std::make_unique<RobotController>(robot, task_list);	 // :152-153
+	BatchedSimulation sim(*robot_controller, 0.001, 1);
+	bool contact_control = false;  // GO_TO_CONTACT / CONTACT_CONTROL (:126)
+	for (int cycle = 0; cycle < ticks; cycle++) {
+		const Batch q = sim.getJointPositions(), dq = sim.getJointVelocities();
+		std::fwrite(q.data(), sizeof(double), q.size(), stdout);
+		std::fwrite(dq.data(), sizeof(double), dq.size(), stdout);
+		robot->setQ(q);	 // :164-166
+		robot->setDq(dq);
+		robot->updateModel();
+		const Batch x = motion_force_task->getCurrentPosition(), R = motion_force_task->getCurrentOrientation();
+		Batch sensed_force(3 * (size_t)B), sensed_moment(3 * (size_t)B);
+		for (int b = 0; b < B; b++) {
+			const double pen = (initial_position[(size_t)2 * B + b] - 0.0005) - x[(size_t)2 * B + b];
+			const double fz = pen > 0 ? -20000.0 * pen : 0.0;
+			// torsional spring: 2 Nm/rad towards the frame's z being vertical, only in contact; z_f = third column of R
+			const double zf[3] = {R[(size_t)2 * B + b], R[(size_t)5 * B + b], R[(size_t)8 * B + b]};
+			const double sgn = zf[2] < 0 ? -1.0 : 1.0, k = pen > 0 ? 2.0 : 0.0;
+			const double mw[3] = {k * sgn * zf[1], -k * sgn * zf[0], 0.0};	// k (z_f x (+-z_world))
+			for (int i = 0; i < 3; i++) {  // into the sensor frame (the link's axes = the control frame's): R^T w
+				sensed_force[(size_t)i * B + b] = R[(size_t)(6 + i) * B + b] * fz;
+				sensed_moment[(size_t)i * B + b] = R[(size_t)i * B + b] * mw[0] + R[(size_t)(3 + i) * B + b] * mw[1];
+			}
+		}
+		motion_force_task->updateSensedForceAndMoment(sensed_force, sensed_moment);	 // :170-171
+		std::fwrite(sensed_force.data(), sizeof(double), sensed_force.size(), stdout);
+		std::fwrite(sensed_moment.data(), sizeof(double), sensed_moment.size(), stdout);
+		robot_controller->updateControllerTaskModels();	 // :174
+		if (!contact_control) {							 // :178-204
+			for (int b = 0; b < B; b++) goal_position[(size_t)2 * B + b] -= 0.00003;
+			motion_force_task->setGoalPosition(goal_position);
+			const Batch fw = motion_force_task->getSensedForceControlWorldFrame();
+			bool all = true;
+			for (int b = 0; b < B; b++) all = all && fw[(size_t)2 * B + b] <= -1.0;
+			if (all) {
+				const double unit_z[3] = {0, 0, 1};
+				motion_force_task->parametrizeForceMotionSpaces(1, unit_z);
+				motion_force_task->parametrizeMomentRotMotionSpaces(2, unit_z);
+				motion_force_task->setClosedLoopForceControl();
+				motion_force_task->setClosedLoopMomentControl();
+				Batch gf(3 * (size_t)B, 0.0), gm(3 * (size_t)B, 0.0);
+				for (int b = 0; b < B; b++) gf[(size_t)2 * B + b] = 10.0;
+				motion_force_task->setGoalForce(gf);
+				motion_force_task->setGoalMoment(gm);
+				motion_force_task->setForceControlGains(0.7, 5.0, 1.5);
+				motion_force_task->setMomentControlGains(0.7, 4.0, 1.5);
+				contact_control = true;
+			}
+		}
+		const Batch flag((size_t)B, contact_control ? 1.0 : 0.0);
+		std::fwrite(flag.data(), sizeof(double), flag.size(), stdout);
+		const Batch control_torques = robot_controller->computeControlTorques();  // :225
+		std::fwrite(control_torques.data(), sizeof(double), control_torques.size(), stdout);
+		sim.integrate();
+	}
+	return contact_control ? 0 : 4;
+}
+
 // examples/11-planar_robot_controller/11-planar_robot_controller.cpp:99-166 call for call: the planar 4R read from its
 // URDF, a partial MotionForceTask (x, y, rotation about z) on "link4" given by name and a JointTask behind it in a
 // RobotController, both with the reference's default internal OTG left on; the goal steps of cycles 0 / 2000 of
@@ -734,6 +817,7 @@ int main(int argc, char** argv) {
 		if (argc >= 6 && std::strcmp(argv[1], "example11") == 0) return example11(std::atoi(argv[2]), argv[3], argv[4], std::atoi(argv[5]));
 		if (argc >= 5 && std::strcmp(argv[1], "example02") == 0) return example02(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example03") == 0) return example03(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
+		if (argc >= 5 && std::strcmp(argv[1], "example07") == 0) return example07(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example09") == 0) return example09(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example18") == 0) return example18(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example01") == 0) return example01(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));

@@ -556,3 +556,66 @@ def test_cpp_example_19_six_r_wrist_singularity(facade_bin, tmp_path):
         singular_periods += int((sing & ~noise).sum())
     assert worst_regular < 1e-9, worst_regular
     assert singular_periods > ticks * B // 10 and skipped < ticks * B // 10, (singular_periods, skipped)
+
+
+@pytest.mark.gpu
+def test_cpp_example_07_surface_surface_contact(facade_bin, tmp_path):
+    """tests/cpp/facade_test.cpp::example07 = examples/07-surface_surface_contact.cpp:124-228 call for call (on the Panda,
+    virtual contact wrench, batch-wide switch): a MotionForceTask parametrised in its compliant frame with the passivity
+    observer on and the force sensor at the link origin; after contact: force control along the frame's z, moment
+    control about its x and y, closed loop both, new force / moment gains."""
+    import oracle_lib as ol
+
+    B, ticks = 32, 500
+    inp = pkg.workloads.make_inputs(3, B=B, seed=707)
+    path = tmp_path / "q.bin"
+    inp["q"].astype(np.float64).tofile(path)
+    r = subprocess.run([facade_bin, "example07", str(B), str(path), str(ticks)], capture_output=True)
+    assert r.returncode == 0, (r.returncode, r.stderr.decode())
+    out = np.frombuffer(r.stdout, dtype=np.float64).reshape(ticks, 28, B)
+    cfg = ol.motion_force_task("surface_alignment_task", frame_pos=(0.0, 0.0, 0.22), internal_otg=False)
+    cfg.parametrization_in_compliant_frame = 1
+    cfg.passivity_enabled = 1
+    cfg.sensor_pos[0], cfg.sensor_pos[1], cfg.sensor_pos[2] = 0.0, 0.0, -0.22  # compliant_frame^-1 * identity
+    o = ol.Oracle(ol.panda_model(), [cfg], B, threads=8)
+    o.set_state(inp["q"], np.zeros_like(inp["q"]))
+    o.reinitialize()
+    goal = o.get_mft_status(0)["pos"].copy()
+    contact, switched_at, worst_regular = False, None, 0.0
+    for cycle in range(ticks):
+        q, dq, sf, sm, flag, tau_g = (out[cycle, :7], out[cycle, 7:14], out[cycle, 14:17], out[cycle, 17:20], out[cycle, 20],
+                                      out[cycle, 21:])
+        o.set_state(q, dq)
+        o.set_mft_sensed_wrench(0, np.ascontiguousarray(sf), np.ascontiguousarray(sm))
+        o.update_task_models()
+        if not contact:
+            goal[2] -= 0.00003
+            o.set_mft_goals(0, goal, None, None, None, None, None)
+            if flag[0] == 1.0:
+                contact, switched_at = True, cycle
+                cfg.force_space_dimension = 1
+                cfg.force_axis[0], cfg.force_axis[1], cfg.force_axis[2] = 0.0, 0.0, 1.0
+                o.update_task_config(0, cfg)
+                cfg.moment_space_dimension = 2
+                cfg.moment_axis[0], cfg.moment_axis[1], cfg.moment_axis[2] = 0.0, 0.0, 1.0
+                o.update_task_config(0, cfg)
+                cfg.closed_loop_force = 1
+                o.update_task_config(0, cfg)
+                cfg.closed_loop_moment = 1
+                o.update_task_config(0, cfg)
+                gf = np.zeros((3, B))
+                gf[2] = 10.0
+                o.set_mft_goal_wrench(0, gf, np.zeros((3, B)))
+                for i in range(3):
+                    cfg.kp_force[i], cfg.kv_force[i], cfg.ki_force[i] = 0.7, 5.0, 1.5
+                o.update_task_config(0, cfg)
+                for i in range(3):
+                    cfg.kp_moment[i], cfg.kv_moment[i], cfg.ki_moment[i] = 0.7, 4.0, 1.5
+                o.update_task_config(0, cfg)
+        tau = o.compute_control_torques(True)
+        _, _, ro = o.get_mft_singularity(0)
+        e = np.abs(tau_g - tau).max(axis=0) / np.maximum(np.abs(tau).max(axis=0), 1)
+        assert e.max() < 1e-5, (cycle, e.max())
+        worst_regular = max(worst_regular, e[ro == 6].max(initial=0.0))
+    assert switched_at is not None and switched_at < ticks - 100, switched_at
+    assert worst_regular < 1e-9, worst_regular
