@@ -7,6 +7,7 @@
 //   facade_test example02 <B> <in> <ticks>   (GPU) example 02: JointTask with the acceleration-limited internal OTG
 //   facade_test example03 <B> <in> <ticks>   (GPU) example 03: MotionForceTask with the Cartesian internal OTG
 //   facade_test example07 <B> <in> <ticks>   (GPU) example 07: surface alignment, force + moment control in the compliant frame
+//   facade_test example08 <B> <in> <ticks>   (GPU) example 08: partial MotionForceTask (y, z, rotation about x) + JointTask
 //   facade_test example09 <B> <in> <ticks>   (GPU) example 09: position control until contact, then force control with POPC
 //   facade_test example18 <B> <in> <ticks>   (GPU) example 18: the Panda driven into its singularities
 //   facade_test example19 <B> <urdf> <in> <ticks>   (GPU) example 19: a 6R arm started in its wrist singularity
@@ -675,6 +676,80 @@ static int example07(int B, const char* path, int ticks) {
 	return contact_control ? 0 : 4;
 }
 
+// examples/08-partial_motion_force_task/08-partial_motion_force_task.cpp:106-200 call for call: a partial
+// MotionForceTask (translation along y and z, rotation about x: a projection that is NOT a leading block) without
+// internal OTG or velocity saturation + a JointTask (internal OTG on) in a RobotController; goal steps the task cannot
+// follow (x, rotation about z) and steps it can, then the first joint moved in the nullspace. Cycles 1000 / 2000 / 3000 /
+// 4000 / 8000 are compressed to k ticks/9. Prints, per period, the state read and the torques.
+static int example08(int B, const char* path, int ticks) {
+	std::ifstream f(path, std::ios::binary);
+	Batch q0(7 * (size_t)B), dq0(7 * (size_t)B, 0.0);
+	f.read((char*)q0.data(), q0.size() * sizeof(double));
+	auto robot = std::make_shared<BatchedRobotModel>(B);
+	robot->setQ(q0);
+	robot->setDq(dq0);
+	robot->updateModel();  // :108
+	const double pos_in_link[3] = {0.07, 0.0, 0.15};									 // "end-effector" (0.07, 0, 0) seen from link7 (:112-114)
+	const std::vector<double> controlled_directions_translation = {0, 1, 0, 0, 0, 1};	 // :115-117
+	const std::vector<double> controlled_directions_rotation = {1, 0, 0};				 // :118-119
+	auto motion_force_task = std::make_shared<MotionForceTask>(robot, 6, controlled_directions_translation, controlled_directions_rotation,
+																pos_in_link);  // :120-122
+	motion_force_task->disableInternalOtg();			 // :124
+	motion_force_task->disableVelocitySaturation();		 // :125
+	motion_force_task->setPosControlGains(100.0, 20.0);	 // :128-129
+	motion_force_task->setOriControlGains(100.0, 20.0);
+	const Batch initial_orientation = motion_force_task->getCurrentOrientation();  // :132-135
+	const Batch initial_position = motion_force_task->getCurrentPosition();
+	Batch goal_position = initial_position, goal_orientation = initial_orientation;
+	auto joint_task = std::make_shared<JointTask>(robot);									   // :138
+	std::vector<std::shared_ptr<TemplateTask>> task_list = {motion_force_task, joint_task};   // :141-142
+	auto robot_controller = std::make_unique<RobotController>(robot, task_list);			   // :143-144
+	joint_task->setGains(100.0, 20.0);														   // :145
+	BatchedSimulation sim(*robot_controller, 0.001, 1);
+	auto rotated = [&](int axis, double angle) {  // AngleAxis(angle, unit axis) * initial_orientation
+		const double c = std::cos(angle), s_ = std::sin(angle);
+		double A[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+		const int i = (axis + 1) % 3, j = (axis + 2) % 3;
+		A[3 * i + i] = c, A[3 * i + j] = -s_, A[3 * j + i] = s_, A[3 * j + j] = c;
+		Batch out(initial_orientation.size());
+		for (int b = 0; b < B; b++)
+			for (int r = 0; r < 3; r++)
+				for (int col = 0; col < 3; col++) {
+					double v = 0;
+					for (int k = 0; k < 3; k++) v += A[3 * r + k] * initial_orientation[(size_t)(3 * k + col) * B + b];
+					out[(size_t)(3 * r + col) * B + b] = v;
+				}
+		return out;
+	};
+	const int u = ticks / 9;
+	for (int cycle = 0; cycle < ticks; cycle++) {
+		const Batch q = sim.getJointPositions(), dq = sim.getJointVelocities();
+		std::fwrite(q.data(), sizeof(double), q.size(), stdout);
+		std::fwrite(dq.data(), sizeof(double), dq.size(), stdout);
+		robot->setQ(q);	 // :155-157
+		robot->setDq(dq);
+		robot->updateModel();
+		robot_controller->updateControllerTaskModels();	 // :160
+		if (cycle == 1 * u)								 // :167-169: x, not controlled
+			for (int b = 0; b < B; b++) goal_position[b] += 0.1;
+		if (cycle == 2 * u)								 // :171-173: y and z
+			for (int b = 0; b < B; b++) goal_position[(size_t)B + b] += 0.1, goal_position[(size_t)2 * B + b] += 0.1;
+		if (cycle == 3 * u) goal_orientation = rotated(2, M_PI / 6);  // :176-179: about z, not controlled
+		if (cycle == 4 * u) goal_orientation = rotated(0, M_PI / 6);  // :181-184: about x
+		if (cycle == 8 * u) {										  // :187-191
+			Batch q_des = robot->q();
+			for (int b = 0; b < B; b++) q_des[b] += 0.5;
+			joint_task->setGoalPosition(q_des);
+		}
+		motion_force_task->setGoalPosition(goal_position);		 // :193-194
+		motion_force_task->setGoalOrientation(goal_orientation);
+		const Batch control_torques = robot_controller->computeControlTorques();  // :199
+		std::fwrite(control_torques.data(), sizeof(double), control_torques.size(), stdout);
+		sim.integrate();
+	}
+	return 0;
+}
+
 // examples/11-planar_robot_controller/11-planar_robot_controller.cpp:99-166 call for call: the planar 4R read from its
 // URDF, a partial MotionForceTask (x, y, rotation about z) on "link4" given by name and a JointTask behind it in a
 // RobotController, both with the reference's default internal OTG left on; the goal steps of cycles 0 / 2000 of
@@ -818,6 +893,7 @@ int main(int argc, char** argv) {
 		if (argc >= 5 && std::strcmp(argv[1], "example02") == 0) return example02(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example03") == 0) return example03(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example07") == 0) return example07(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
+		if (argc >= 5 && std::strcmp(argv[1], "example08") == 0) return example08(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example09") == 0) return example09(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example18") == 0) return example18(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example01") == 0) return example01(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));

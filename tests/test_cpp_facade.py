@@ -619,3 +619,68 @@ def test_cpp_example_07_surface_surface_contact(facade_bin, tmp_path):
         worst_regular = max(worst_regular, e[ro == 6].max(initial=0.0))
     assert switched_at is not None and switched_at < ticks - 100, switched_at
     assert worst_regular < 1e-9, worst_regular
+
+
+@pytest.mark.gpu
+def test_cpp_example_08_partial_motion_force_task(facade_bin, tmp_path):
+    """tests/cpp/facade_test.cpp::example08 = examples/08-partial_motion_force_task.cpp:106-200 call for call: a partial
+    MotionForceTask whose projection is not a leading block (y, z, rotation about x) + JointTask in a RobotController
+    (the SVD-free kernel's PU^T J path in closed loop), goal steps inside and outside the controlled directions."""
+    import oracle_lib as ol
+
+    B, ticks = 64, 540
+    inp = pkg.workloads.make_inputs(3, B=B, seed=808)
+    path = tmp_path / "q.bin"
+    inp["q"].astype(np.float64).tofile(path)
+    r = subprocess.run([facade_bin, "example08", str(B), str(path), str(ticks)], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    out = np.frombuffer(r.stdout, dtype=np.float64).reshape(ticks, 3, 7, B)
+    partial = (np.array([[0, 1.0, 0], [0, 0, 1.0]]), np.array([[1.0, 0, 0]]))
+    mcfg = ol.motion_force_task("partial_motion_force_task", frame_pos=(0.07, 0.0, 0.15), partial=partial, internal_otg=False)
+    mcfg.use_velocity_saturation = 0
+    for i in range(3):
+        mcfg.kp_pos[i], mcfg.kv_pos[i], mcfg.ki_pos[i] = 100.0, 20.0, 0.0
+        mcfg.kp_ori[i], mcfg.kv_ori[i], mcfg.ki_ori[i] = 100.0, 20.0, 0.0
+    jcfg = ol.joint_task("joint_task", internal_otg=True)
+    for i in range(7):
+        jcfg.kp[i], jcfg.kv[i], jcfg.ki[i] = 100.0, 20.0, 0.0
+    o = ol.Oracle(ol.panda_model(), [mcfg, jcfg], B, threads=8)
+    o.set_state(inp["q"], np.zeros_like(inp["q"]))
+    o.reinitialize()
+    st = o.get_mft_status(0)
+    gp, R0 = st["pos"].copy(), st["rot"].reshape(3, 3, B).copy()
+    gR = R0
+
+    def rotated(axis, angle):
+        c, s = np.cos(angle), np.sin(angle)
+        A = np.eye(3)
+        i, j = (axis + 1) % 3, (axis + 2) % 3
+        A[i, i], A[i, j], A[j, i], A[j, j] = c, -s, s, c
+        return np.einsum("ik,kjb->ijb", A, R0)
+
+    u = ticks // 9
+    worst_regular = 0.0
+    for cycle in range(ticks):
+        q, dq, tau_g = out[cycle]
+        o.set_state(q, dq)
+        o.update_task_models()
+        if cycle == u:
+            gp[0] += 0.1
+        if cycle == 2 * u:
+            gp[1] += 0.1
+            gp[2] += 0.1
+        if cycle == 3 * u:
+            gR = rotated(2, np.pi / 6)
+        if cycle == 4 * u:
+            gR = rotated(0, np.pi / 6)
+        if cycle == 8 * u:
+            qd = q.copy()
+            qd[0] += 0.5
+            o.set_jt_goals(1, qd)
+        o.set_mft_goals(0, gp, np.ascontiguousarray(gR.reshape(9, B)), None, None, None, None)
+        tau = o.compute_control_torques(True)
+        _, _, ro = o.get_mft_singularity(0)
+        e = np.abs(tau_g - tau).max(axis=0) / np.maximum(np.abs(tau).max(axis=0), 1)
+        assert e.max() < 1e-5, (cycle, e.max())
+        worst_regular = max(worst_regular, e[ro == 3].max(initial=0.0))
+    assert worst_regular < 1e-9, worst_regular
