@@ -51,6 +51,10 @@ struct sai2b_ctx {
 	bool fb_seen_pending = false;
 	int cert_probe = 0, cert_backoff = 0;
 	bool last_tick_generic_only = false;
+	// sai2b_update_task_models() is deferred: the reference's loop is update -> goal setters -> computeControlTorques,
+	// and the fused tick (with the SVD-free kernels in front) does both at once. Any other call in between runs the
+	// pending model update first (flush_update), so nothing observable changes.
+	bool update_pending = false;
 	// The tasks' _current_position / _current_orientation are those of the last torque computation (or
 	// re-initialisation), and enabling an OTG starts its generator there (JointTask.cpp:374-376). While
 	// the state buffer still holds that state nothing is kept; the first write to it afterwards
@@ -88,6 +92,8 @@ struct sai2b_ctx {
 	long long launches = 0, ticks = 0;
 	std::string error;
 };
+
+static int flush_update(sai2b_ctx* ctx);  // runs a deferred sai2b_update_task_models() now
 
 static int set_error(sai2b_ctx* ctx, int code, const std::string& msg) {
 	g_error = msg;
@@ -749,6 +755,7 @@ static bool space_changed(int dim, const double* axis, int old_dim, const double
 
 extern "C" int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_task_config* cfg) {
 	if (!ctx || !cfg || task < 0 || task >= ctx->T) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_update_task_config: bad arguments");
+	if (int rc_ = flush_update(ctx)) return rc_;
 	const sai2b_task_config& old = ctx->cfg[task];
 	if (cfg->type != old.type || cfg->task_dof != old.task_dof || cfg->link != old.link ||
 		std::memcmp(cfg->joint_selection, old.joint_selection, sizeof(old.joint_selection)) != 0 ||
@@ -814,6 +821,7 @@ extern "C" int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_ta
 
 extern "C" int sai2b_enable_gravity_compensation(sai2b_ctx* ctx, int enable) {
 	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	if (int rc_ = flush_update(ctx)) return rc_;
 	ctx->h_params.gravity_comp = enable ? 1 : 0;
 	ctx->params_dirty = true;
 	return SAI2B_OK;
@@ -856,6 +864,7 @@ static int keep_pose(sai2b_ctx* ctx) {
 
 extern "C" int sai2b_set_state(sai2b_ctx* ctx, const double* q, const double* dq, int on_device) {
 	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	if (int rc_ = flush_update(ctx)) return rc_;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	int rc;
 	if (q && (rc = keep_pose(ctx))) return rc;
@@ -922,6 +931,7 @@ extern "C" int sai2b_set_jt_goals(sai2b_ctx* ctx, int task, const double* q_goal
 
 extern "C" int sai2b_reinitialize(sai2b_ctx* ctx) {
 	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	if (int rc_ = flush_update(ctx)) return rc_;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	int rc = upload_params(ctx);
 	if (rc) return rc;
@@ -1077,17 +1087,34 @@ static int fetch_tau(sai2b_ctx* ctx, double* tau, int on_device) {
 // The split API recomputes the (deterministic) task models inside compute_control_torques; what
 // update_task_models() adds is the once-per-tick singularity bookkeeping, which is why it is
 // committed there and not again by the torque pass that follows it (DESIGN.md "split API").
-extern "C" int sai2b_update_task_models(sai2b_ctx* ctx) {
-	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+static int flush_update(sai2b_ctx* ctx) {
+	if (!ctx || !ctx->update_pending) return SAI2B_OK;
+	ctx->update_pending = false;
 	int rc = launch_tick(ctx, /*commit_sh=*/1, /*with_comp=*/1, /*do_torque=*/0);
 	if (rc) return rc;
 	ctx->models_fresh = true;
 	return SAI2B_OK;
 }
+extern "C" int sai2b_update_task_models(sai2b_ctx* ctx) {
+	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	if (int rc_ = flush_update(ctx)) return rc_;  // an update still pending: it happens now, this one is the new pending one
+	if (ctx->introspection) {  // the introspection outputs of the model pass are read between the two calls
+		int rc = launch_tick(ctx, /*commit_sh=*/1, /*with_comp=*/1, /*do_torque=*/0);
+		if (rc) return rc;
+		ctx->models_fresh = true;
+		return SAI2B_OK;
+	}
+	ctx->update_pending = true;
+	return SAI2B_OK;
+}
 
 extern "C" int sai2b_compute_control_torques_ex(sai2b_ctx* ctx, double* tau, int on_device, int with_compensation) {
 	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
-	int rc = launch_tick(ctx, ctx->models_fresh ? 0 : 1, with_compensation, 1);
+	// a pending update is consumed here: update + torques as ONE fused tick (once-per-update singularity bookkeeping
+	// committed by it, exactly as by the model pass it replaces)
+	const bool fused = ctx->update_pending;
+	ctx->update_pending = false;
+	int rc = launch_tick(ctx, (fused || !ctx->models_fresh) ? 1 : 0, with_compensation, 1);
 	if (rc) return rc;
 	ctx->models_fresh = false;
 	ctx->ticks += ctx->B;
@@ -1099,6 +1126,7 @@ extern "C" int sai2b_compute_control_torques(sai2b_ctx* ctx, double* tau, int on
 
 extern "C" int sai2b_tick(sai2b_ctx* ctx, double* tau, int on_device) {
 	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	if (int rc_ = flush_update(ctx)) return rc_;
 	int rc = launch_tick(ctx, 1, 1, 1);
 	if (rc) return rc;
 	ctx->models_fresh = false;
@@ -1113,6 +1141,7 @@ static int task_io(sai2b_ctx* ctx, int task, const char* fn) {
 	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
 	if (task < 0 || task >= ctx->T) return set_error(ctx, SAI2B_INVALID_ARGUMENT, std::string(fn) + ": bad task index");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (int rc_ = flush_update(ctx)) return rc_;
 	sai2b_ctx::TaskIO& io = ctx->tio[task];
 	if (!io.N) {
 		const size_t B = ctx->B;
@@ -1188,6 +1217,7 @@ extern "C" int sai2b_task_compute_torques(sai2b_ctx* ctx, int task, const double
 
 extern "C" int sai2b_task_reinitialize(sai2b_ctx* ctx, int task) {
 	if (!ctx || task < 0 || task >= ctx->T) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_task_reinitialize: bad arguments");
+	if (int rc_ = flush_update(ctx)) return rc_;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	int rc = upload_params(ctx);
 	if (rc) return rc;
@@ -1219,6 +1249,7 @@ extern "C" int sai2b_task_get_nullspaces(sai2b_ctx* ctx, int task, double* N_tas
 
 extern "C" int sai2b_synchronize(sai2b_ctx* ctx) {
 	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	if (int rc_ = flush_update(ctx)) return rc_;
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return SAI2B_OK;
 }
@@ -1231,6 +1262,7 @@ extern "C" int sai2b_set_caller_stream(sai2b_ctx* ctx, void* stream) {
 
 extern "C" void* sai2b_device_buffer(sai2b_ctx* ctx, int which, int task) {
 	if (!ctx) return nullptr;
+	if (flush_update(ctx)) return nullptr;
 	const bool task_ok = task >= 0 && task < ctx->T;
 	switch (which) {
 		case SAI2B_BUF_Q: return ctx->q;
@@ -1247,6 +1279,7 @@ extern "C" void* sai2b_device_buffer(sai2b_ctx* ctx, int which, int task) {
 
 extern "C" int sai2b_enable_introspection(sai2b_ctx* ctx, int enable) {
 	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	if (int rc_ = flush_update(ctx)) return rc_;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	if (enable && !ctx->h_params.dbg_M) {
 		const size_t B = ctx->B;
@@ -1281,15 +1314,18 @@ static int fetch_dbg(sai2b_ctx* ctx, double* dst, const double* src, size_t rows
 
 extern "C" int sai2b_get_task_nullspace(sai2b_ctx* ctx, int task, double* N_total) {
 	if (!ctx || task < 0 || task >= ctx->T) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "bad task index");
+	if (int rc_ = flush_update(ctx)) return rc_;
 	return fetch_dbg(ctx, N_total, ctx->h_params.task[task].dbg_N, N * N);
 }
 extern "C" int sai2b_get_task_torques(sai2b_ctx* ctx, int task, double* tau_task) {
 	if (!ctx || task < 0 || task >= ctx->T) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "bad task index");
+	if (int rc_ = flush_update(ctx)) return rc_;
 	return fetch_dbg(ctx, tau_task, ctx->h_params.task[task].dbg_tau, N);
 }
 extern "C" int sai2b_get_mft_singularity(sai2b_ctx* ctx, int task, double* sigma, double* alpha, double* ns_rank) {
 	int rc = mft_task_check(ctx, task, "sai2b_get_mft_singularity");
 	if (rc) return rc;
+	if ((rc = flush_update(ctx))) return rc;
 	const double* s = ctx->h_params.task[task].dbg_sigma;
 	const size_t B = ctx->B;
 	if ((rc = fetch_dbg(ctx, sigma, s, 6))) return rc;
@@ -1301,6 +1337,7 @@ extern "C" int sai2b_get_mft_singularity(sai2b_ctx* ctx, int task, double* sigma
 extern "C" int sai2b_get_mft_singularity_state(sai2b_ctx* ctx, int task, int* n_singular, int* type_1_count, int* type_2_count) {
 	int rc = mft_task_check(ctx, task, "sai2b_get_mft_singularity_state");
 	if (rc) return rc;
+	if ((rc = flush_update(ctx))) return rc;
 	const int* IS = ctx->h_params.task[task].istate;
 	const size_t B = ctx->B;
 	int* dst[3] = {n_singular, type_1_count, type_2_count};
@@ -1313,6 +1350,7 @@ extern "C" int sai2b_get_mft_singularity_state(sai2b_ctx* ctx, int task, int* n_
 extern "C" int sai2b_get_mft_task_forces(sai2b_ctx* ctx, int task, double* F_unit, double* F_force) {
 	int rc = mft_task_check(ctx, task, "sai2b_get_mft_task_forces");
 	if (rc) return rc;
+	if ((rc = flush_update(ctx))) return rc;
 	const double* F = ctx->h_params.task[task].dbg_F;
 	if ((rc = fetch_dbg(ctx, F_unit, F, 6))) return rc;
 	return fetch_dbg(ctx, F_force, F ? F + 6 * (size_t)ctx->B : nullptr, 6);
@@ -1328,6 +1366,7 @@ static int fetch_rows(sai2b_ctx* ctx, const double* src, size_t row0, size_t row
 // ---- simulation harness ----
 extern "C" int sai2b_sim_step(sai2b_ctx* ctx, const double* tau, int on_device, double dt, int substeps, int with_gravity) {
 	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	if (int rc_ = flush_update(ctx)) return rc_;
 	if (!(dt > 0) || substeps < 1 || substeps > 1000) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_sim_step: dt must be > 0 and substeps in [1, 1000]");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	int rc = upload_params(ctx);
@@ -1403,6 +1442,7 @@ extern "C" int sai2b_get_mft_sigma(sai2b_ctx* ctx, int task, double* sigma_force
 extern "C" int sai2b_set_mft_type1_posture(sai2b_ctx* ctx, int task, const double* q_des, int on_device) {
 	int rc = mft_task_check(ctx, task, "sai2b_set_mft_type1_posture");
 	if (rc) return rc;
+	if ((rc = flush_update(ctx))) return rc;
 	if (!q_des) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_set_mft_type1_posture: null posture");
 	return copy_rows(ctx, ctx->h_params.task[task].state + (size_t)sai2b::MFT_QPRIOR * ctx->B, q_des, N, on_device);
 }
@@ -1502,6 +1542,7 @@ extern "C" int sai2b_get_otg_status(sai2b_ctx* ctx, int task, double* goal_reach
 
 extern "C" int sai2b_get_model(sai2b_ctx* ctx, int task, double* M, double* J, double* pos, double* rot) {
 	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
+	if (int rc_ = flush_update(ctx)) return rc_;
 	int rc;
 	if ((rc = fetch_dbg(ctx, M, ctx->h_params.dbg_M, N * N))) return rc;
 	if (!J && !pos && !rot) return SAI2B_OK;
@@ -1519,6 +1560,7 @@ extern "C" int sai2b_get_model(sai2b_ctx* ctx, int task, double* M, double* J, d
 // one, the generic kernel over its work list behind it (0 otherwise).
 extern "C" int sai2b_profile_tick(sai2b_ctx* ctx, int steps, double* first_ms, double* second_ms) {
 	if (!ctx || steps < 1) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_profile_tick: bad arguments");
+	if (int rc_ = flush_update(ctx)) return rc_;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	int rc = upload_params(ctx);
 	if (rc) return rc;
@@ -1555,6 +1597,7 @@ extern "C" int sai2b_profile_tick(sai2b_ctx* ctx, int steps, double* first_ms, d
 
 extern "C" int sai2b_get_fallback_count(sai2b_ctx* ctx, int* robots) {
 	if (!ctx || !robots) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_get_fallback_count: bad arguments");
+	if (int rc_ = flush_update(ctx)) return rc_;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	if (ctx->last_tick_generic_only) {	// no SVD-free kernel ran in front: every robot took the generic kernel
 		*robots = ctx->B;

@@ -690,3 +690,41 @@ def test_force_space_reparametrisation_side_effects():
     change(closed_loop_force=True)
     for _ in range(2):
         assert _err(g.tick(), o.tick()).max() < TOL
+
+
+def test_split_calls_run_the_fused_tick_and_flush_when_observed():
+    """sai2b_update_task_models() is deferred and consumed by the torque call behind it (the reference's loop runs the
+    same kernels as tick()); anything else in between — here the singularity counters, a state change — makes the
+    model update happen first, so what a caller can observe is unchanged."""
+    B = 2048
+    inp = pkg.workloads.make_inputs(3, B=B, seed=77)
+    q = inp["q"].copy()
+    q[3, :5] = -0.0715  # a few robots inside the blending region: the once-per-update bookkeeping is visible
+    inp["q"] = q
+    o, g = _pair(inp, introspection=False)
+    ol.load_inputs(o, inp)
+    ol.load_inputs(g, inp)
+    l0 = g.counters()[0]
+    for c in (o, g):
+        c.update_task_models()
+    assert g.counters()[0] == l0  # nothing launched yet
+    tau_o, tau_g = o.compute_control_torques(True), g.compute_control_torques(True)
+    assert g.counters()[0] == l0 + 1 and 5 <= g.fallback_count() < 64  # one fused tick: SVD-free kernel + its work list
+    _, _, ro = o.get_mft_singularity(0)
+    e = _err(tau_g, tau_o)
+    assert e[ro == 6].max() < TOL and e.max() < 1e-6
+    # observed in between: the update runs when asked about its result, the torque pass does not commit it again
+    for c in (o, g):
+        c.update_task_models()
+    n_g = g.get_singularity_types_count(0)
+    assert g.counters()[0] == l0 + 2 and (n_g[:5] > 0).all() and (n_g[5:] == 0).all()
+    tau_o, tau_g = o.compute_control_torques(True), g.compute_control_torques(True)
+    e = _err(tau_g, tau_o)
+    assert e[ro == 6].max() < TOL and e.max() < 1e-6
+    # a new state between the two calls: the pending update belongs to the OLD state
+    for c in (o, g):
+        c.update_task_models()
+        c.set_state(inp["q"], 0.5 * inp["dq"])
+    tau_o, tau_g = o.compute_control_torques(True), g.compute_control_torques(True)
+    e = _err(tau_g, tau_o)
+    assert e[ro == 6].max() < 1e-9 and e.max() < 1e-5
