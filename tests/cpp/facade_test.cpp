@@ -6,6 +6,7 @@
 //                               tasks driven through the TemplateTask virtuals with no RobotController
 //   facade_test example02 <B> <in> <ticks>   (GPU) example 02: JointTask with the acceleration-limited internal OTG
 //   facade_test example03 <B> <in> <ticks>   (GPU) example 03: MotionForceTask with the Cartesian internal OTG
+//   facade_test example05 <B> <in> <ticks>   (GPU) example 05: MotionForceTask + JointTask through a RobotController
 //   facade_test example07 <B> <in> <ticks>   (GPU) example 07: surface alignment, force + moment control in the compliant frame
 //   facade_test example08 <B> <in> <ticks>   (GPU) example 08: partial MotionForceTask (y, z, rotation about x) + JointTask
 //   facade_test example09 <B> <in> <ticks>   (GPU) example 09: position control until contact, then force control with POPC
@@ -594,6 +595,77 @@ static int example09(int B, const char* path, int ticks) {
 	return force_control ? 0 : 4;  // the scenario must have reached the force-control phase
 }
 
+// examples/05-using_robot_controller/05-using_robot_controller.cpp:103-196 call for call: the example04 trajectories
+// driven through a RobotController (updateControllerTaskModels / computeControlTorques: the two calls run the fused
+// tick, i.e. the SVD-free kernel of the headline benchmark), the joint goal stepped at cycle 5000 = ticks/2. Prints,
+// per period, the state read and the torques.
+static int example05(int B, const char* path, int ticks) {
+	std::ifstream f(path, std::ios::binary);
+	Batch q0(7 * (size_t)B), dq0(7 * (size_t)B, 0.0);
+	f.read((char*)q0.data(), q0.size() * sizeof(double));
+	auto robot = std::make_shared<BatchedRobotModel>(B);
+	robot->setQ(q0);
+	robot->setDq(dq0);
+	robot->updateModel();  // :106
+	const double pos_in_link[3] = {0.0, 0.0, 0.22};	 // "end-effector" (0, 0, 0.07) seen from link7 (:111-113)
+	auto motion_force_task = std::make_shared<MotionForceTask>(robot, 6, pos_in_link);	// :114-115
+	motion_force_task->disableInternalOtg();											// :117
+	const Batch initial_orientation = motion_force_task->getCurrentOrientation();		// :120-122
+	const Batch initial_position = motion_force_task->getCurrentPosition();
+	const Batch initial_q = robot->q();													// :123
+	auto joint_task = std::make_shared<JointTask>(robot);								// :126
+	std::vector<std::shared_ptr<TemplateTask>> task_list = {motion_force_task, joint_task};	 // :129-130
+	auto robot_controller = std::make_unique<RobotController>(robot, task_list);			 // :131-132
+	BatchedSimulation sim(*robot_controller, 0.001, 1);
+	for (int cycle = 0; cycle < ticks; cycle++) {
+		const double time = 0.001 * cycle;
+		const Batch q = sim.getJointPositions(), dq = sim.getJointVelocities();
+		std::fwrite(q.data(), sizeof(double), q.size(), stdout);
+		std::fwrite(dq.data(), sizeof(double), dq.size(), stdout);
+		robot->setQ(q);	 // :143-145
+		robot->setDq(dq);
+		robot->updateModel();
+		robot_controller->updateControllerTaskModels();	 // :148
+		const double w_ori = 2 * M_PI * 0.2, amp = M_PI / 8, ang = amp * std::sin(w_ori * time);  // :153-160
+		const double c = std::cos(ang), s_ = std::sin(ang);
+		const double Rt[9] = {c, 0, -s_, 0, 1, 0, s_, 0, c};  // R^T for a rotation by ang about Y
+		Batch Rg(9 * (size_t)B), wg(3 * (size_t)B, 0.0), ag(3 * (size_t)B, 0.0), pg(3 * (size_t)B), vg(3 * (size_t)B), lg(3 * (size_t)B);
+		const double r = 0.05, wc = 2 * M_PI * 0.33;
+		const double dp[3] = {0.0, std::sin(wc * time), 1 - std::cos(wc * time)}, dv[3] = {0.0, std::cos(wc * time), std::sin(wc * time)},
+					 da[3] = {0.0, -std::sin(wc * time), std::cos(wc * time)};
+		for (int b = 0; b < B; b++) {
+			for (int i = 0; i < 3; i++)
+				for (int j = 0; j < 3; j++) {
+					double v = 0;
+					for (int k = 0; k < 3; k++) v += Rt[3 * i + k] * initial_orientation[(size_t)(3 * k + j) * B + b];
+					Rg[(size_t)(3 * i + j) * B + b] = v;
+				}
+			wg[(size_t)1 * B + b] = amp * w_ori * std::cos(w_ori * time);
+			ag[(size_t)1 * B + b] = amp * w_ori * w_ori * -std::sin(w_ori * time);
+			for (int i = 0; i < 3; i++) {
+				pg[(size_t)i * B + b] = initial_position[(size_t)i * B + b] + r * dp[i];
+				vg[(size_t)i * B + b] = r * wc * dv[i];
+				lg[(size_t)i * B + b] = r * wc * wc * da[i];
+			}
+		}
+		motion_force_task->setGoalOrientation(Rg);			 // :164-169
+		motion_force_task->setGoalAngularVelocity(wg);
+		motion_force_task->setGoalAngularAcceleration(ag);
+		motion_force_task->setGoalPosition(pg);				 // :174-183
+		motion_force_task->setGoalLinearVelocity(vg);
+		motion_force_task->setGoalLinearAcceleration(lg);
+		if (cycle == ticks / 2) {							 // :185-190
+			Batch goal_joint_pos = initial_q;
+			for (int b = 0; b < B; b++) goal_joint_pos[b] += 1.5;
+			joint_task->setGoalPosition(goal_joint_pos);
+		}
+		const Batch control_torques = robot_controller->computeControlTorques();  // :195
+		std::fwrite(control_torques.data(), sizeof(double), control_torques.size(), stdout);
+		sim.integrate();
+	}
+	return 0;
+}
+
 // examples/07-surface_surface_contact/07-surface_surface_contact.cpp:124-228 call for call on the Panda: one 6-DOF
 // MotionForceTask parametrised in its COMPLIANT frame, passivity observer on, force sensor at the link origin
 // (setForceSensorFrame(link, identity)), sinking until contact, then force control along the frame's z and moment
@@ -892,6 +964,7 @@ int main(int argc, char** argv) {
 		if (argc >= 6 && std::strcmp(argv[1], "example11") == 0) return example11(std::atoi(argv[2]), argv[3], argv[4], std::atoi(argv[5]));
 		if (argc >= 5 && std::strcmp(argv[1], "example02") == 0) return example02(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example03") == 0) return example03(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
+		if (argc >= 5 && std::strcmp(argv[1], "example05") == 0) return example05(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example07") == 0) return example07(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example08") == 0) return example08(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example09") == 0) return example09(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));

@@ -684,3 +684,53 @@ def test_cpp_example_08_partial_motion_force_task(facade_bin, tmp_path):
         assert e.max() < 1e-5, (cycle, e.max())
         worst_regular = max(worst_regular, e[ro == 3].max(initial=0.0))
     assert worst_regular < 1e-9, worst_regular
+
+
+@pytest.mark.gpu
+def test_cpp_example_05_using_robot_controller(facade_bin, tmp_path):
+    """tests/cpp/facade_test.cpp::example05 = examples/05-using_robot_controller.cpp:103-196 call for call: the BASELINE
+    hierarchy (MotionForceTask + nullspace JointTask with its default internal OTG) through a RobotController in closed
+    loop; updateControllerTaskModels() + computeControlTorques() run the fused tick (the headline SVD-free kernel)."""
+    import oracle_lib as ol
+
+    B, ticks = 256, 300
+    inp = pkg.workloads.make_inputs(3, B=B, seed=505)
+    path = tmp_path / "q.bin"
+    inp["q"].astype(np.float64).tofile(path)
+    r = subprocess.run([facade_bin, "example05", str(B), str(path), str(ticks)], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    out = np.frombuffer(r.stdout, dtype=np.float64).reshape(ticks, 3, 7, B)
+    o = ol.Oracle(ol.panda_model(), [ol.motion_force_task("motion_force_task"), ol.joint_task("joint_task", internal_otg=True)], B, threads=8)
+    o.set_state(inp["q"], np.zeros_like(inp["q"]))
+    o.reinitialize()
+    st = o.get_mft_status(0)
+    x0, R0 = st["pos"].copy(), st["rot"].reshape(3, 3, B).copy()
+    worst_regular = 0.0
+    for cycle in range(ticks):
+        q, dq, tau_g = out[cycle]
+        t = 0.001 * cycle
+        o.set_state(q, dq)
+        o.update_task_models()
+        w_ori, amp = 2 * np.pi * 0.2, np.pi / 8
+        ang = amp * np.sin(w_ori * t)
+        c, s = np.cos(ang), np.sin(ang)
+        Rt = np.array([[c, 0, -s], [0, 1, 0], [s, 0, c]])
+        Rg = np.einsum("ik,kjb->ijb", Rt, R0).reshape(9, B)
+        wg, ag = np.zeros((3, B)), np.zeros((3, B))
+        wg[1], ag[1] = amp * w_ori * np.cos(w_ori * t), amp * w_ori * w_ori * -np.sin(w_ori * t)
+        r_, wc = 0.05, 2 * np.pi * 0.33
+        dp = np.array([0.0, np.sin(wc * t), 1 - np.cos(wc * t)])[:, None]
+        dv = np.array([0.0, np.cos(wc * t), np.sin(wc * t)])[:, None]
+        da = np.array([0.0, -np.sin(wc * t), np.cos(wc * t)])[:, None]
+        o.set_mft_goals(0, x0 + r_ * dp, np.ascontiguousarray(Rg), np.broadcast_to(r_ * wc * dv, (3, B)), wg,
+                        np.broadcast_to(r_ * wc * wc * da, (3, B)), ag)
+        if cycle == ticks // 2:
+            g = inp["q"].copy()
+            g[0] += 1.5
+            o.set_jt_goals(1, g)
+        tau = o.compute_control_torques(True)
+        _, _, ro = o.get_mft_singularity(0)
+        e = np.abs(tau_g - tau).max(axis=0) / np.maximum(np.abs(tau).max(axis=0), 1)
+        assert e.max() < 1e-5, (cycle, e.max())
+        worst_regular = max(worst_regular, e[ro == 6].max(initial=0.0))
+    assert worst_regular < 1e-9, worst_regular
