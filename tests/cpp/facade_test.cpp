@@ -9,6 +9,7 @@
 //   facade_test example05 <B> <in> <ticks>   (GPU) example 05: MotionForceTask + JointTask through a RobotController
 //   facade_test example07 <B> <in> <ticks>   (GPU) example 07: surface alignment, force + moment control in the compliant frame
 //   facade_test example08 <B> <in> <ticks>   (GPU) example 08: partial MotionForceTask (y, z, rotation about x) + JointTask
+//   facade_test example10 <B> <in> <ticks>   (GPU) example 10: orientation-only MotionForceTask + JointTask
 //   facade_test example09 <B> <in> <ticks>   (GPU) example 09: position control until contact, then force control with POPC
 //   facade_test example18 <B> <in> <ticks>   (GPU) example 18: the Panda driven into its singularities
 //   facade_test example19 <B> <urdf> <in> <ticks>   (GPU) example 19: a 6R arm started in its wrist singularity
@@ -822,6 +823,66 @@ static int example08(int B, const char* path, int ticks) {
 	return 0;
 }
 
+// examples/10-3d_orientation_controller/10-3d_orientation_controller.cpp:101-166 call for call on the Panda: an
+// orientation-only MotionForceTask (three rotation directions, no translation; internal OTG on) + JointTask in a
+// RobotController, the goal orientation stepped between three attitudes; cycles 0 / 2000 / 4000 of 6000 are compressed
+// to 0 / ticks/3 / 2 ticks/3. Prints, per period, the state read and the torques.
+static int example10(int B, const char* path, int ticks) {
+	std::ifstream f(path, std::ios::binary);
+	Batch q0(7 * (size_t)B), dq0(7 * (size_t)B, 0.0);
+	f.read((char*)q0.data(), q0.size() * sizeof(double));
+	auto robot = std::make_shared<BatchedRobotModel>(B);
+	robot->setQ(q0);
+	robot->setDq(dq0);
+	robot->updateModel();  // :104
+	const double pos_in_link[3] = {0.0, 0.0, 0.0};
+	const std::vector<double> controlled_directions_translation = {};					  // :108
+	const std::vector<double> controlled_directions_rotation = {1, 0, 0, 0, 1, 0, 0, 0, 1};	  // :109-112
+	auto motion_force_task = std::make_shared<MotionForceTask>(robot, 6, controlled_directions_translation, controlled_directions_rotation,
+																pos_in_link);  // :113-115
+	const Batch initial_orientation = motion_force_task->getCurrentOrientation();  // :118
+	Batch goal_orientation = initial_orientation;
+	auto joint_task = std::make_shared<JointTask>(robot);									   // :122
+	std::vector<std::shared_ptr<TemplateTask>> task_list = {motion_force_task, joint_task};   // :123-124
+	auto robot_controller = std::make_unique<RobotController>(robot, task_list);			   // :125-126
+	BatchedSimulation sim(*robot_controller, 0.001, 1);
+	auto premultiplied = [&](const double A[9]) {
+		Batch out(initial_orientation.size());
+		for (int b = 0; b < B; b++)
+			for (int r = 0; r < 3; r++)
+				for (int col = 0; col < 3; col++) {
+					double v = 0;
+					for (int k = 0; k < 3; k++) v += A[3 * r + k] * initial_orientation[(size_t)(3 * k + col) * B + b];
+					out[(size_t)(3 * r + col) * B + b] = v;
+				}
+		return out;
+	};
+	const double cx = std::cos(M_PI / 3), sx = std::sin(M_PI / 3), cy = std::cos(M_PI / 4), sy = std::sin(M_PI / 4);
+	const double Rx[9] = {1, 0, 0, 0, cx, -sx, 0, sx, cx};
+	const double RyRx[9] = {cy, sy * sx, sy * cx, 0, cx, -sx, -sy, cy * sx, cy * cx};  // Ry(pi/4) Rx(pi/3)
+	const int period = ticks;
+	for (int cycle = 0; cycle < ticks; cycle++) {
+		const Batch q = sim.getJointPositions(), dq = sim.getJointVelocities();
+		std::fwrite(q.data(), sizeof(double), q.size(), stdout);
+		std::fwrite(dq.data(), sizeof(double), dq.size(), stdout);
+		robot->setQ(q);	 // :136-138
+		robot->setDq(dq);
+		robot->updateModel();
+		robot_controller->updateControllerTaskModels();	 // :141
+		if (cycle % period == 0)						 // :147-158
+			goal_orientation = initial_orientation;
+		else if (cycle % period == period / 3)
+			goal_orientation = premultiplied(Rx);
+		else if (cycle % period == 2 * period / 3)
+			goal_orientation = premultiplied(RyRx);
+		motion_force_task->setGoalOrientation(goal_orientation);				  // :160
+		const Batch control_torques = robot_controller->computeControlTorques();  // :165
+		std::fwrite(control_torques.data(), sizeof(double), control_torques.size(), stdout);
+		sim.integrate();
+	}
+	return 0;
+}
+
 // examples/11-planar_robot_controller/11-planar_robot_controller.cpp:99-166 call for call: the planar 4R read from its
 // URDF, a partial MotionForceTask (x, y, rotation about z) on "link4" given by name and a JointTask behind it in a
 // RobotController, both with the reference's default internal OTG left on; the goal steps of cycles 0 / 2000 of
@@ -967,6 +1028,7 @@ int main(int argc, char** argv) {
 		if (argc >= 5 && std::strcmp(argv[1], "example05") == 0) return example05(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example07") == 0) return example07(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example08") == 0) return example08(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
+		if (argc >= 5 && std::strcmp(argv[1], "example10") == 0) return example10(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example09") == 0) return example09(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example18") == 0) return example18(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 5 && std::strcmp(argv[1], "example01") == 0) return example01(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));

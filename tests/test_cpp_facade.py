@@ -734,3 +734,48 @@ def test_cpp_example_05_using_robot_controller(facade_bin, tmp_path):
         assert e.max() < 1e-5, (cycle, e.max())
         worst_regular = max(worst_regular, e[ro == 6].max(initial=0.0))
     assert worst_regular < 1e-9, worst_regular
+
+
+@pytest.mark.gpu
+def test_cpp_example_10_orientation_controller(facade_bin, tmp_path):
+    """tests/cpp/facade_test.cpp::example10 = examples/10-3d_orientation_controller.cpp:101-166 call for call (on the
+    Panda): an orientation-only MotionForceTask with its default internal OTG + JointTask in a RobotController, the
+    goal attitude stepped by 60 and 45 degrees."""
+    import oracle_lib as ol
+
+    B, ticks = 64, 600
+    inp = pkg.workloads.make_inputs(3, B=B, seed=1010)
+    path = tmp_path / "q.bin"
+    inp["q"].astype(np.float64).tofile(path)
+    r = subprocess.run([facade_bin, "example10", str(B), str(path), str(ticks)], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    out = np.frombuffer(r.stdout, dtype=np.float64).reshape(ticks, 3, 7, B)
+    partial = (np.zeros((0, 3)), np.eye(3))
+    cfg = [ol.motion_force_task("partial_motion_force_task", frame_pos=(0.0, 0.0, 0.0), partial=partial, internal_otg=True),
+           ol.joint_task("joint_task", internal_otg=True)]
+    o = ol.Oracle(ol.panda_model(), cfg, B, threads=8)
+    o.set_state(inp["q"], np.zeros_like(inp["q"]))
+    o.reinitialize()
+    R0 = o.get_mft_status(0)["rot"].reshape(3, 3, B).copy()
+    cx, sx, cy, sy = np.cos(np.pi / 3), np.sin(np.pi / 3), np.cos(np.pi / 4), np.sin(np.pi / 4)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    gR = R0
+    worst_regular = 0.0
+    for cycle in range(ticks):
+        q, dq, tau_g = out[cycle]
+        o.set_state(q, dq)
+        o.update_task_models()
+        if cycle == 0:
+            gR = R0
+        elif cycle == ticks // 3:
+            gR = np.einsum("ik,kjb->ijb", Rx, R0)
+        elif cycle == 2 * ticks // 3:
+            gR = np.einsum("ik,kjb->ijb", Ry @ Rx, R0)
+        o.set_mft_goals(0, None, np.ascontiguousarray(gR.reshape(9, B)), None, None, None, None)
+        tau = o.compute_control_torques(True)
+        _, _, ro = o.get_mft_singularity(0)
+        e = np.abs(tau_g - tau).max(axis=0) / np.maximum(np.abs(tau).max(axis=0), 1)
+        assert e.max() < 1e-5, (cycle, e.max())
+        worst_regular = max(worst_regular, e[ro == 3].max(initial=0.0))
+    assert worst_regular < 1e-9, worst_regular
