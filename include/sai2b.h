@@ -330,7 +330,12 @@ enum sai2b_buffer {
 	SAI2B_BUF_TAU = 2,	  /* [7][B]  */
 	SAI2B_BUF_GOALS = 3,  /* per task; MFT: [30][B] = pos3 rot9 v3 w3 a3 alpha3 f3 m3; JT: [3k][B] */
 	SAI2B_BUF_SENSED = 4, /* per MFT task: [6][B] sensor-frame force, moment */
-	SAI2B_BUF_STATE = 5	  /* per task persistent state, see DESIGN.md */
+	SAI2B_BUF_STATE = 5,  /* per task persistent state, see DESIGN.md */
+	/* outputs of the task-level calls (sai2b_task_update_model), [n*n][B]: a manual hierarchy chains them on the device —
+	 * sai2b_task_update_model(ctx, next, sai2b_device_buffer(ctx, SAI2B_BUF_TASK_N_TOTAL, task), 1) — instead of through
+	 * sai2b_task_get_nullspaces() and the host. NULL before the task's first task-level call. */
+	SAI2B_BUF_TASK_N = 6,		/* the task's nullspace N (getTaskNullspace) */
+	SAI2B_BUF_TASK_N_TOTAL = 7	/* N * N_prec (getTaskAndPreviousNullspace) */
 };
 /* (A producer that writes q through SAI2B_BUF_Q bypasses the bookkeeping of the tasks' cached pose: an OTG
  * enabled / a space re-parametrised after such a write and before the next tick starts from the state as

@@ -19,7 +19,7 @@ FULL_DYNAMIC_DECOUPLING, BOUNDED_INERTIA_ESTIMATES, IMPEDANCE = 0, 1, 2
 # enum sai2b_status
 OK, INVALID_ARGUMENT, RUNTIME_ERROR, UNSUPPORTED = 0, 1, 2, 3
 # enum sai2b_buffer
-BUF_Q, BUF_DQ, BUF_TAU, BUF_GOALS, BUF_SENSED, BUF_STATE = 0, 1, 2, 3, 4, 5
+BUF_Q, BUF_DQ, BUF_TAU, BUF_GOALS, BUF_SENSED, BUF_STATE, BUF_TASK_N, BUF_TASK_N_TOTAL = 0, 1, 2, 3, 4, 5, 6, 7
 
 _d = C.c_double
 _i = C.c_int

@@ -243,6 +243,14 @@ class Controller:
         p, _ = self._in(N_prec, self.dof * self.dof)
         self._rc(self.lib.sai2b_task_update_model(self.h, task, p, self._dev(N_prec)))
 
+    def task_update_model_behind(self, task, previous_task):
+        """updateTaskModel(previous->getTaskAndPreviousNullspace()) without the host round trip of the [n*n][B] matrix:
+        the previous task's N * N_prec is read where its own update left it on the device (same context, same stream)"""
+        p = self.lib.sai2b_device_buffer(self.h, _abi.BUF_TASK_N_TOTAL, int(previous_task))
+        if not p:
+            raise ValueError("task_update_model_behind: the previous task has no task-level model yet")
+        self._rc(self.lib.sai2b_task_update_model(self.h, task, C.c_void_p(p), 1))
+
     def task_compute_torques(self, task, tau_prec=None, out=None):
         """TemplateTask::computeTorques() / computeTorques(tau_prec): the task's own torques [n][B]"""
         p, _ = self._in(tau_prec, self.dof)

@@ -1273,6 +1273,8 @@ extern "C" void* sai2b_device_buffer(sai2b_ctx* ctx, int which, int task) {
 			return task_ok ? ctx->h_params.task[task].goals : nullptr;
 		case SAI2B_BUF_SENSED: return task_ok ? ctx->h_params.task[task].sensed : nullptr;
 		case SAI2B_BUF_STATE: return task_ok ? ctx->h_params.task[task].state : nullptr;
+		case SAI2B_BUF_TASK_N: return task_ok ? ctx->tio[task].N : nullptr;
+		case SAI2B_BUF_TASK_N_TOTAL: return task_ok ? ctx->tio[task].Ntot : nullptr;
 	}
 	return nullptr;
 }

@@ -225,3 +225,23 @@ def test_device_inputs_follow_the_callers_stream():
         dq_dev.fill_(-7.0)
     tau = g.tick()
     assert np.array_equal(tau, tau_ref)
+
+
+def test_manual_hierarchy_chained_on_the_device():
+    """SAI2B_BUF_TASK_N_TOTAL: the next task of a hand-chained hierarchy reads N * N_prec where the previous task's
+    update left it on the device; same torques as the chain through the host"""
+    import oracle_lib as ol
+
+    B = 256
+    inp = pkg.workloads.make_inputs(3, B=B, seed=14)
+    g = pkg.Controller(pkg.panda_model(), pkg.task_configs(inp["tasks"]), B)
+    ol.load_inputs(g, inp)
+    g.task_update_model(0, None)
+    g.task_update_model(1, g.task_nullspaces(0)[2])
+    ref = g.task_compute_torques(0) + g.task_compute_torques(1)
+    g.task_update_model(0, None)
+    g.task_update_model_behind(1, 0)
+    tau = g.task_compute_torques(0) + g.task_compute_torques(1)
+    assert np.array_equal(tau, ref)
+    with pytest.raises(ValueError):
+        pkg.Controller(pkg.panda_model(), pkg.task_configs(inp["tasks"]), B).task_update_model_behind(1, 0)
