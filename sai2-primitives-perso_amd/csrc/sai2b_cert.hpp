@@ -22,7 +22,8 @@
 // and the bounded-inertia / impedance variants below; for d = 1 these are the rank-one formulas of sai2b_fast.hpp.
 //
 // State (integrators) is written only once the robot is known to finish here: the values wait in LDS
-// (PEND_SLOTS doubles per lane).
+// (PEND_SLOTS doubles per lane). Partial tasks of up to 6 rows (the kernel's instantiations: MCAP = 3 and 6);
+// the host routes anything else to the generic kernel (sai2b_host.cpp: cert_kind).
 #pragma once
 #include "sai2b_device.hpp"
 #include "sai2b_fast.hpp"
@@ -52,7 +53,6 @@ __device__ int g_cstamp_n;
 #define CSTAMP(id) do { } while (0)
 #endif
 
-constexpr int MM = N > 6 ? N : 6;  // most rows one task brings (MotionForceTask: 6, JointTask: N)
 constexpr int DM = N - 1;		   // largest nullspace a full JointTask behind another task can see
 constexpr int PEND_SLOTS = 36;	   // deferred stores per robot: gravity N, MotionForceTask 12, JointTask k0
 constexpr int LB_SLOTS = N * (N + 1) / 2 + N;  // factor of the bounded inertia estimate, parked in LDS between its uses
