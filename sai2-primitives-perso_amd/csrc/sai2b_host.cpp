@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -35,6 +36,7 @@ struct sai2b_ctx {
 	bool params_dirty = true;
 	bool baked_model = false;  // the ctx model is bit-equal to the compile-time Panda constants
 	bool no_fast_path = false;	// SAI2B_NO_FAST_PATH=1 in the environment: always run the generic kernel
+	bool blocking_sync = false;	// SAI2B_BLOCKING_SYNC=1: sai2b_synchronize() blocks without polling first
 	bool no_cert_path = false;	// SAI2B_NO_CERT_PATH=1: no SVD-free kernel for general hierarchies (sai2b_cert.hpp)
 	// lanes per robot of the generic kernel: SAI2B_GENERIC_LANES = 16 / 8 / 1 (1: the one-lane-per-robot kernel),
 	// default 0 = by the amount of work (generic_lanes())
@@ -627,6 +629,8 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	ctx->model = *model;
 	const char* nf = std::getenv("SAI2B_NO_FAST_PATH");
 	ctx->no_fast_path = nf && nf[0] == '1';
+	const char* bs = std::getenv("SAI2B_BLOCKING_SYNC");
+	ctx->blocking_sync = bs && bs[0] == '1';
 	const char* nc = std::getenv("SAI2B_NO_CERT_PATH");
 	ctx->no_cert_path = nc && nc[0] == '1';
 	if (const char* gl = std::getenv("SAI2B_GENERIC_LANES")) ctx->generic_lanes_env = std::atoi(gl);
@@ -1250,6 +1254,18 @@ extern "C" int sai2b_task_get_nullspaces(sai2b_ctx* ctx, int task, double* N_tas
 extern "C" int sai2b_synchronize(sai2b_ctx* ctx) {
 	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
 	if (int rc_ = flush_update(ctx)) return rc_;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	// poll for up to ~2 ms before blocking: a control loop waits for ticks of tens of microseconds, and the wake-up
+	// of a blocking wait is of that order (SAI2B_BLOCKING_SYNC=1: block at once)
+	if (!ctx->blocking_sync) {
+		const auto t0 = std::chrono::steady_clock::now();
+		for (int spin = 0;; spin++) {
+			const hipError_t e = hipStreamQuery(ctx->stream);
+			if (e == hipSuccess) return SAI2B_OK;
+			if (e != hipErrorNotReady) break;  // let the blocking call report it
+			if ((spin & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+		}
+	}
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return SAI2B_OK;
 }
