@@ -883,13 +883,8 @@ DI void tick_robot(const DevParams& P, int b, real* pad, int commit_sh, int with
 		spd_inverse_rows<G, N>(rb.minv);
 		GMARK(16, "model_minv_done");
 		// bounded inertia estimate (SingularityHandler.cpp:176-182, JointTask.cpp:254-260), shared
-		bool any_bie = false;
-		real thr = 0;
-		for (int t = 0; t < P.n_tasks; t++)
-			if (P.task[t].decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES) {
-				any_bie = true;
-				thr = P.task[t].bie_threshold;
-			}
+		const bool any_bie = P.any_bie != 0;  // (host: upload_params)
+		const real thr = P.bie_thr;
 		if (any_bie) {
 			UNROLL for (int j = 0; j < N; j++) rb.minvB[j] = (j == rb.r) ? fmax(Mrow[j], thr) : Mrow[j];
 			spd_inverse_rows<G, N>(rb.minvB);
