@@ -11,7 +11,7 @@
  *   - Eigen::VectorXd / MatrixXd become `Batch` = std::vector<double> in SoA layout [C][B]
  *     (component-major, batch-minor; matrices row-major inside the component index);
  *   - errors: std::invalid_argument for the reference's argument checks, std::runtime_error for HIP.
- * An Eigen-typed adapter for batch == 1 is a "next" row.
+ * The Eigen-typed adapter for batch == 1 is Sai2PrimitivesEigen.h.
  */
 #ifndef SAI2_PRIMITIVES_BATCHED_H_
 #define SAI2_PRIMITIVES_BATCHED_H_
@@ -25,7 +25,13 @@
 
 #include "sai2b.h"
 
-namespace Sai2Primitives {
+// The facade's namespace is the reference's; Sai2PrimitivesEigen.h, which re-creates the reference's Eigen-typed
+// classes on top of this one for a batch of one, moves it aside.
+#ifndef SAI2B_FACADE_NAMESPACE
+#define SAI2B_FACADE_NAMESPACE Sai2Primitives
+#endif
+
+namespace SAI2B_FACADE_NAMESPACE {
 
 using Batch = std::vector<double>;
 
@@ -1040,6 +1046,6 @@ inline void MotionForceTask::flushGoals() {
 	for (auto& b : _g) b.clear();
 }
 
-}  // namespace Sai2Primitives
+}  // namespace SAI2B_FACADE_NAMESPACE (Sai2Primitives)
 
 #endif	// SAI2_PRIMITIVES_BATCHED_H_

@@ -779,3 +779,71 @@ def test_cpp_example_10_orientation_controller(facade_bin, tmp_path):
         assert e.max() < 1e-5, (cycle, e.max())
         worst_regular = max(worst_regular, e[ro == 3].max(initial=0.0))
     assert worst_regular < 1e-9, worst_regular
+
+
+@pytest.fixture(scope="module")
+def eigen_bin(tmp_path_factory):
+    """tests/cpp/eigen_adapter_test.cpp against include/Sai2PrimitivesEigen.h; Eigen itself is not in this image, the
+    program compiles against tests/cpp/mini_eigen (a test double of the few Eigen operations used)"""
+    pkg._abi.load_library()
+    out = str(tmp_path_factory.mktemp("cpp") / "eigen_adapter_test")
+    subprocess.run(
+        ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "cpp", "mini_eigen"),
+         os.path.join(ROOT, "tests", "cpp", "eigen_adapter_test.cpp"), "-o", out, "-L", CSRC, "-lsai2b", f"-Wl,-rpath,{CSRC}",
+         "-Wl,-rpath,/opt/rocm/lib"],
+        check=True,
+    )
+    return out
+
+
+def test_eigen_adapter_compiles(eigen_bin):
+    assert os.path.exists(eigen_bin)
+
+
+@pytest.mark.gpu
+def test_eigen_adapter_runs_example_05_with_the_references_own_types(eigen_bin, tmp_path):
+    """include/Sai2PrimitivesEigen.h: the reference's signatures (shared_ptr<Sai2Model::Sai2Model>, Affine3d, Vector3d,
+    Matrix3d, VectorXd) for one robot. tests/cpp/eigen_adapter_test.cpp is example 05 as a reference user wrote it; its
+    torques against the oracle, period by period."""
+    import oracle_lib as ol
+    from test_urdf import _urdf_from_model
+
+    ticks = 300
+    urdf = tmp_path / "panda_arm.urdf"
+    urdf.write_text(_urdf_from_model(pkg.panda_model()))
+    q0 = pkg.workloads.make_inputs(3, B=4, seed=55)["q"][:, :1].copy()
+    path = tmp_path / "q.bin"
+    np.ascontiguousarray(q0[:, 0]).tofile(path)
+    r = subprocess.run([eigen_bin, str(urdf), str(path), str(ticks)], capture_output=True)
+    assert r.returncode == 0, (r.returncode, r.stderr.decode())
+    out = np.frombuffer(r.stdout, dtype=np.float64).reshape(ticks, 3, 7, 1)
+    m, links = pkg.model_from_urdf(str(urdf))
+    link, fpos, frot = pkg.resolve_link_frame(links, "end-effector", (0.0, 0.0, 0.07))
+    o = ol.Oracle(m, [ol.motion_force_task("motion_force_task", link, fpos, frot), ol.joint_task("joint_task", internal_otg=True)], 1)
+    o.set_state(q0, np.zeros_like(q0))
+    o.reinitialize()
+    st = o.get_mft_status(0)
+    x0, R0 = st["pos"].copy(), st["rot"].reshape(3, 3, 1).copy()
+    for cycle in range(ticks):
+        q, dq, tau_g = out[cycle]
+        t = 0.001 * cycle
+        o.set_state(q, dq)
+        o.update_task_models()
+        w_ori, amp = 2 * np.pi * 0.2, np.pi / 8
+        ang = amp * np.sin(w_ori * t)
+        c, s = np.cos(ang), np.sin(ang)
+        Rt = np.array([[c, 0, -s], [0, 1, 0], [s, 0, c]])
+        Rg = np.einsum("ik,kjb->ijb", Rt, R0).reshape(9, 1)
+        wg, ag = np.zeros((3, 1)), np.zeros((3, 1))
+        wg[1], ag[1] = amp * w_ori * np.cos(w_ori * t), amp * w_ori * w_ori * -np.sin(w_ori * t)
+        r_, wc = 0.05, 2 * np.pi * 0.33
+        dp = np.array([0.0, np.sin(wc * t), 1 - np.cos(wc * t)])[:, None]
+        dv = np.array([0.0, np.cos(wc * t), np.sin(wc * t)])[:, None]
+        da = np.array([0.0, -np.sin(wc * t), np.cos(wc * t)])[:, None]
+        o.set_mft_goals(0, x0 + r_ * dp, np.ascontiguousarray(Rg), r_ * wc * dv, wg, r_ * wc * wc * da, ag)
+        if cycle == ticks // 2:
+            g = q0.copy()
+            g[0] += 1.5
+            o.set_jt_goals(1, g)
+        tau = o.compute_control_torques(True)
+        assert _err(tau_g, tau) < 1e-9, (cycle, _err(tau_g, tau))

@@ -297,7 +297,7 @@ def _SPLIT_BOUND(B):
     the bit-reproducible sine / cosine / arctangent of include/sai2b_detmath.h on both sides left 5 of 300 seeds with
     such robots (one seed 38 of 128), all traced to the pose the generators are (re)initialised at: the forward
     kinematics of the two sides differed in the last bit. With include/sai2b_detfk.h (one IEEE operation sequence for
-    that pose on both sides) the generators see identical bits: 10 000 seeds, no robot. An exploratory sweep may still
+    that pose on both sides) the generators see identical bits: 16 000 seeds, no robot. An exploratory sweep may still
     set SAI2B_FUZZ_SPLIT_FRACTION."""
     frac = os.environ.get("SAI2B_FUZZ_SPLIT_FRACTION")
     return int(float(frac) * B) if frac else 0
