@@ -4,7 +4,8 @@
 // written for the reference looks like when it only swaps the include. (Eigen itself is not in this image: the test
 // compiles against tests/cpp/mini_eigen, a test double of the handful of Eigen operations used here; with the real
 // Eigen on the include path nothing else changes.) The simulation of the example is Sai2PrimitivesBatched's.
-//   eigen_adapter_test <urdf> <q0 file> <ticks>   prints, per period: q, dq read from the simulation and the torques
+//   eigen_adapter_test <urdf> <q0 file> <ticks> [manual]   prints, per period: q, dq read from the simulation and the
+//   torques; `manual`: example 04's hand-chained hierarchy instead of the RobotController
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -45,6 +46,37 @@ int main(int argc, char** argv) {
 
 		// joint task in the nullspace of the motion-force task (:125-126)
 		auto joint_task = make_shared<Sai2Primitives::JointTask>(robot);
+
+		if (argc > 4 && string(argv[4]) == "manual") {
+			// examples/04-task_and_redundancy.cpp:141-150,188-206: no controller, the nullspace handed from task to task as
+			// a MatrixXd (a non-symmetric matrix: the adapter's row- / column-major conversions are on this path)
+			Sai2PrimitivesBatched::BatchedSimulation sim(*motion_force_task->batched(), 0.001, 1);
+			MatrixXd N_prec = MatrixXd::Identity(dof, dof);
+			for (int cycle = 0; cycle < ticks; cycle++) {
+				const vector<double> qs = sim.getJointPositions(), dqs = sim.getJointVelocities();
+				fwrite(qs.data(), sizeof(double), qs.size(), stdout);
+				fwrite(dqs.data(), sizeof(double), dqs.size(), stdout);
+				VectorXd q(dof), dq(dof);
+				for (int i = 0; i < dof; i++) q(i) = qs[(size_t)i], dq(i) = dqs[(size_t)i];
+				robot->setQ(q);
+				robot->setDq(dq);
+				robot->updateModel();
+				N_prec = MatrixXd::Identity(dof, dof);
+				motion_force_task->updateTaskModel(N_prec);
+				N_prec = motion_force_task->getTaskAndPreviousNullspace();
+				joint_task->updateTaskModel(N_prec);
+				motion_force_task->setGoalPosition(initial_position + Vector3d(0.0, 0.05, -0.03));
+				VectorXd motion_force_task_torques = motion_force_task->computeTorques();
+				VectorXd joint_task_torques = joint_task->computeTorques();
+				VectorXd control_torques = motion_force_task_torques + joint_task_torques;
+				vector<double> out((size_t)dof);
+				for (int i = 0; i < dof; i++) out[(size_t)i] = control_torques(i);
+				fwrite(out.data(), sizeof(double), out.size(), stdout);
+				sim.setJointTorques(out);
+				sim.integrate();
+			}
+			return 0;
+		}
 
 		// robot controller (:128-132)
 		vector<shared_ptr<Sai2Primitives::TemplateTask>> task_list = {motion_force_task, joint_task};

@@ -847,3 +847,35 @@ def test_eigen_adapter_runs_example_05_with_the_references_own_types(eigen_bin, 
             o.set_jt_goals(1, g)
         tau = o.compute_control_torques(True)
         assert _err(tau_g, tau) < 1e-9, (cycle, _err(tau_g, tau))
+
+
+@pytest.mark.gpu
+def test_eigen_adapter_manual_hierarchy(eigen_bin, tmp_path):
+    """the TemplateTask-level calls with Eigen types (examples/04-task_and_redundancy.cpp:141-150,188-206): the nullspace
+    travels from task to task as a MatrixXd — the adapter's row- / column-major conversions of a non-symmetric matrix"""
+    import oracle_lib as ol
+    from test_urdf import _urdf_from_model
+
+    ticks = 40
+    urdf = tmp_path / "panda_arm.urdf"
+    urdf.write_text(_urdf_from_model(pkg.panda_model()))
+    q0 = pkg.workloads.make_inputs(3, B=4, seed=56)["q"][:, :1].copy()
+    path = tmp_path / "q.bin"
+    np.ascontiguousarray(q0[:, 0]).tofile(path)
+    r = subprocess.run([eigen_bin, str(urdf), str(path), str(ticks), "manual"], capture_output=True)
+    assert r.returncode == 0, (r.returncode, r.stderr.decode())
+    out = np.frombuffer(r.stdout, dtype=np.float64).reshape(ticks, 3, 7, 1)
+    m, links = pkg.model_from_urdf(str(urdf))
+    link, fpos, frot = pkg.resolve_link_frame(links, "end-effector", (0.0, 0.0, 0.07))
+    o = ol.Oracle(m, [ol.motion_force_task("motion_force_task", link, fpos, frot), ol.joint_task("joint_task", internal_otg=True)], 1)
+    o.set_state(q0, np.zeros_like(q0))
+    o.reinitialize()
+    x0 = o.get_mft_status(0)["pos"].copy()
+    for cycle in range(ticks):
+        q, dq, tau_g = out[cycle]
+        o.set_state(q, dq)
+        o.task_update_model(0, np.eye(7).reshape(49, 1))
+        o.task_update_model(1, o.task_nullspaces(0)[2])
+        o.set_mft_goals(0, x0 + np.array([[0.0], [0.05], [-0.03]]), None, None, None, None, None)
+        tau = o.task_compute_torques(0) + o.task_compute_torques(1)
+        assert _err(tau_g, tau) < 1e-9, (cycle, _err(tau_g, tau))
