@@ -52,6 +52,7 @@ struct sai2b_ctx {
 	hipEvent_t fb_seen_ev = nullptr;
 	bool fb_seen_pending = false;
 	int cert_probe = 0, cert_backoff = 0;
+	int fb_last_seen = -1;		// length of the work list when the host last looked (-1: never)
 	bool last_tick_generic_only = false;
 	// sai2b_update_task_models() is deferred: the reference's loop is update -> goal setters -> computeControlTorques,
 	// and the fused tick (with the SVD-free kernels in front) does both at once. Any other call in between runs the
@@ -1058,7 +1059,8 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 	if (fast_wanted && fast >= 3) {	 // the kernel for general hierarchies: only while it keeps most of the batch
 		if (ctx->fb_seen_pending && hipEventQuery(ctx->fb_seen_ev) == hipSuccess) {
 			ctx->fb_seen_pending = false;
-			if ((long long)*ctx->fb_seen * 5 > (long long)ctx->B * 2) ctx->cert_backoff = 64;
+			ctx->fb_last_seen = *ctx->fb_seen;
+			if ((long long)ctx->fb_last_seen * 5 > (long long)ctx->B * 2) ctx->cert_backoff = 64;
 		}
 		if (ctx->cert_backoff > 0) {
 			ctx->cert_backoff--;
@@ -1068,7 +1070,9 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 	const bool fast_launch = fast_wanted && fast_now != 0;
 	ctx->last_tick_generic_only = do_torque && commit_sh && !fast_launch && !ctx->introspection;
 	if (fast_launch) ctx->fb_parity ^= 1;
-	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast_now, ctx->baked_model ? 1 : 0, commit_sh, with_comp, do_torque, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, !fast_launch), ctx->stream))
+	// a long work list (thousands of robots) is throughput, not latency: two robots per DPP row, as for a whole batch
+	const bool long_list = fast_launch && fast >= 3 && ctx->fb_last_seen > 8192;
+	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast_now, ctx->baked_model ? 1 : 0, commit_sh, with_comp, do_torque, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, !fast_launch || long_list), ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
 	ctx->launches++;
 	if (fast_launch && fast >= 3 && !ctx->fb_seen_pending && (ctx->cert_probe++ & 7) == 0) {
