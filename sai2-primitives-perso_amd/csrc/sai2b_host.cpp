@@ -1071,7 +1071,7 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 	ctx->last_tick_generic_only = do_torque && commit_sh && !fast_launch && !ctx->introspection;
 	if (fast_launch) ctx->fb_parity ^= 1;
 	// a long work list (thousands of robots) is throughput, not latency: two robots per DPP row, as for a whole batch
-	const bool long_list = fast_launch && fast >= 3 && ctx->fb_last_seen > 8192;
+	const bool long_list = fast_launch && fast >= 3 && ctx->fb_last_seen > 4096;  // (16 lanes: 4 robots x 1024 wavefronts in one round)
 	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast_now, ctx->baked_model ? 1 : 0, commit_sh, with_comp, do_torque, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, !fast_launch || long_list), ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
 	ctx->launches++;
