@@ -38,6 +38,7 @@ struct sai2b_ctx {
 	bool no_fast_path = false;	// SAI2B_NO_FAST_PATH=1 in the environment: always run the generic kernel
 	bool blocking_sync = false;	// SAI2B_BLOCKING_SYNC=1: sai2b_synchronize() blocks without polling first
 	bool no_cert_path = false;	// SAI2B_NO_CERT_PATH=1: no SVD-free kernel for general hierarchies (sai2b_cert.hpp)
+	bool prefer_cert = false;	// SAI2B_PREFER_CERT=1 (diagnostic): sai2b_cert.hpp also where sai2b_fast.hpp applies
 	// lanes per robot of the generic kernel: SAI2B_GENERIC_LANES = 16 / 8 / 1 (1: the one-lane-per-robot kernel),
 	// default 0 = by the amount of work (generic_lanes())
 	int generic_lanes_env = 0;
@@ -634,6 +635,8 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	ctx->blocking_sync = bs && bs[0] == '1';
 	const char* nc = std::getenv("SAI2B_NO_CERT_PATH");
 	ctx->no_cert_path = nc && nc[0] == '1';
+	const char* pc = std::getenv("SAI2B_PREFER_CERT");
+	ctx->prefer_cert = pc && pc[0] == '1';
 	if (const char* gl = std::getenv("SAI2B_GENERIC_LANES")) ctx->generic_lanes_env = std::atoi(gl);
 	DevParams& hp = ctx->h_params;
 	std::memset(&hp, 0, sizeof(hp));
@@ -985,6 +988,7 @@ static int fast_kind(const sai2b_ctx* ctx) {
 		!ctx->h_params.task[0].full_projection || ctx->h_params.task[0].rank != 6 ||
 		(ctx->cfg[0].passivity_enabled && ctx->cfg[0].closed_loop_force))
 		return cert_kind(ctx);
+	if (ctx->prefer_cert && cert_kind(ctx)) return cert_kind(ctx);
 	if (ctx->T == 1) return 1;
 	return (ctx->cfg[1].type == SAI2B_JOINT_TASK && ctx->h_params.task[1].full_selection) ? 2 : cert_kind(ctx);
 }

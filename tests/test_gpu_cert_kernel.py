@@ -94,3 +94,23 @@ def test_cert_kernel_backs_off_when_it_declines_most_of_the_batch():
     m, kinds, o, g, q, dq = tr._setup("six_r", 1, False, False, seed=5)
     for tick in range(3):
         assert _err(g.tick(), o.tick()).max() < 1e-9
+
+
+@pytest.mark.parametrize("config", [2, 3])
+def test_six_row_instantiation_on_the_full_motion_force_task(config, monkeypatch):
+    """SAI2B_PREFER_CERT=1 (read when a controller is created) sends [MFT(6)] and [MFT(6), JT(7)] — normally
+    sai2b_fast.hpp's — through tick_cert_kernel<6>: a second, independently written SVD-free path for the headline
+    workload. Same 1e-10 against the oracle, and the two GPU paths agree with each other."""
+    B = 2048 + 11
+    inp = pkg.workloads.make_inputs(config, B=B, seed=4200 + config)
+    o, g_fast = _pair(inp)
+    monkeypatch.setenv("SAI2B_PREFER_CERT", "1")
+    g_cert = pkg.Controller(pkg.panda_model(), pkg.task_configs(inp["tasks"]), B)
+    monkeypatch.delenv("SAI2B_PREFER_CERT")
+    for c in (o, g_fast, g_cert):
+        ol.load_inputs(c, inp)
+    for tick in range(2):
+        tau_o, tau_f, tau_c = o.tick(), g_fast.tick(), g_cert.tick()
+        assert _err(tau_c, tau_o).max() < TOL
+        assert _err(tau_c, tau_f).max() < TOL
+        assert g_cert.fallback_count() == 0
