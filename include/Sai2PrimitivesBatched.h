@@ -87,6 +87,23 @@ public:
 		detail::check(nullptr, sai2b_urdf_resolve_frame(&_links, link_name.c_str(), pos_in_link, rot_in_link, &link, frame_pos, frame_rot));
 		return link;
 	}
+	// Sai2Model::setTRobotBase(T_world_base) (examples/05-using_robot_controller/05-using_robot_controller.cpp:69): the
+	// pose of the robot's base in the world; replaces an earlier one. The tasks work in the world frame
+	// (MotionForceTask.cpp:100-103, 262: positionInWorld / rotationInWorld / JWorldFrame) and gravity is a world vector,
+	// so this is part of the model the kernels see (sai2b_model_set_base_transform) — to be called, as the reference's
+	// examples do, before a controller or a task is built on this model. rot: row-major 3 x 3, nullptr = identity.
+	void setTRobotBase(const double pos[3], const double* rot) {
+		if (_controller || !_standalone.empty())
+			throw std::invalid_argument("setTRobotBase must be called before a controller or a task runs on this robot model");
+		if (!_has_base) _model_in_base = _model, _has_base = true;
+		sai2b_robot_model m = _model_in_base;
+		detail::check(nullptr, sai2b_model_set_base_transform(&m, pos, rot));
+		_model = m;
+		for (int i = 0; i < 3; i++) _base_pos[i] = pos[i];
+		for (int i = 0; i < 9; i++) _base_rot[i] = rot ? rot[i] : (i % 4 == 0 ? 1.0 : 0.0);
+	}
+	const double* TRobotBasePosition() const { return _base_pos; }	// Sai2Model::TRobotBase(), translation
+	const double* TRobotBaseRotation() const { return _base_rot; }	// ... and rotation, row-major
 	int dof() const { return _model.dof; }
 	int batch() const { return _batch; }
 	int device() const { return _device; }
@@ -113,6 +130,9 @@ private:
 	std::vector<sai2b_ctx*> _standalone;  // contexts of tasks driven on their own (TemplateTask-level calls)
 	int _batch, _device;
 	sai2b_robot_model _model;
+	sai2b_robot_model _model_in_base;  // as loaded, before setTRobotBase
+	bool _has_base = false;
+	double _base_pos[3] = {0, 0, 0}, _base_rot[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 	sai2b_urdf_links _links;
 	bool _has_links = false;
 	Batch _q, _dq;

@@ -106,9 +106,27 @@ public:
 	void setQ(const Eigen::VectorXd& q) { _impl->setQ(Sai2PrimitivesEigenDetail::batch_of(q)); }
 	void setDq(const Eigen::VectorXd& dq) { _impl->setDq(Sai2PrimitivesEigenDetail::batch_of(dq)); }
 	void updateModel() { _impl->updateModel(); }  // kinematics and dynamics are recomputed on the device every tick
-	// pose of a frame attached to a link, in the world frame (= the robot base frame here)
-	Eigen::Vector3d position(const std::string& link_name, const Eigen::Vector3d& pos_in_link = Eigen::Vector3d::Zero()) const {
-		Eigen::Affine3d T = transform(link_name);
+	// Sai2Model::setTRobotBase / TRobotBase: the pose of the robot base in the world (examples/05-...cpp:69); the tasks
+	// work in the world frame, so this goes into the model the kernels see — before tasks are built on the robot
+	void setTRobotBase(const Eigen::Affine3d& T) {
+		double p[3], R[9];
+		for (int i = 0; i < 3; i++) {
+			p[i] = T.translation()(i);
+			for (int j = 0; j < 3; j++) R[3 * i + j] = T.linear()(i, j);
+		}
+		_impl->setTRobotBase(p, R);
+	}
+	Eigen::Affine3d TRobotBase() const {
+		Eigen::Affine3d T = Eigen::Affine3d::Identity();
+		for (int i = 0; i < 3; i++) {
+			T.translation()(i) = _impl->TRobotBasePosition()[i];
+			for (int j = 0; j < 3; j++) T.linear()(i, j) = _impl->TRobotBaseRotation()[3 * i + j];
+		}
+		return T;
+	}
+	// pose of a frame attached to a link: ...InWorld in the world frame, the plain ones in the robot's base frame
+	Eigen::Vector3d positionInWorld(const std::string& link_name, const Eigen::Vector3d& pos_in_link = Eigen::Vector3d::Zero()) const {
+		Eigen::Affine3d T = transformInWorld(link_name);
 		Eigen::Vector3d p;
 		for (int i = 0; i < 3; i++) {
 			p(i) = T.translation()(i);
@@ -116,11 +134,18 @@ public:
 		}
 		return p;
 	}
-	Eigen::Vector3d positionInWorld(const std::string& link_name, const Eigen::Vector3d& pos_in_link = Eigen::Vector3d::Zero()) const {
-		return position(link_name, pos_in_link);
+	Eigen::Vector3d position(const std::string& link_name, const Eigen::Vector3d& pos_in_link = Eigen::Vector3d::Zero()) const {
+		const Eigen::Vector3d pw = positionInWorld(link_name, pos_in_link);
+		const double *pb = _impl->TRobotBasePosition(), *Rb = _impl->TRobotBaseRotation();
+		Eigen::Vector3d p;
+		for (int i = 0; i < 3; i++) {
+			p(i) = 0;
+			for (int k = 0; k < 3; k++) p(i) += Rb[3 * k + i] * (pw(k) - pb[k]);
+		}
+		return p;
 	}
-	Eigen::Matrix3d rotation(const std::string& link_name, const Eigen::Matrix3d& rot_in_link = Eigen::Matrix3d::Identity()) const {
-		Eigen::Affine3d T = transform(link_name);
+	Eigen::Matrix3d rotationInWorld(const std::string& link_name, const Eigen::Matrix3d& rot_in_link = Eigen::Matrix3d::Identity()) const {
+		Eigen::Affine3d T = transformInWorld(link_name);
 		Eigen::Matrix3d R;
 		for (int i = 0; i < 3; i++)
 			for (int j = 0; j < 3; j++) {
@@ -129,12 +154,26 @@ public:
 			}
 		return R;
 	}
-	Eigen::Matrix3d rotationInWorld(const std::string& link_name, const Eigen::Matrix3d& rot_in_link = Eigen::Matrix3d::Identity()) const {
-		return rotation(link_name, rot_in_link);
+	Eigen::Matrix3d rotation(const std::string& link_name, const Eigen::Matrix3d& rot_in_link = Eigen::Matrix3d::Identity()) const {
+		const Eigen::Matrix3d Rw = rotationInWorld(link_name, rot_in_link);
+		const double* Rb = _impl->TRobotBaseRotation();
+		Eigen::Matrix3d R;
+		for (int i = 0; i < 3; i++)
+			for (int j = 0; j < 3; j++) {
+				R(i, j) = 0;
+				for (int k = 0; k < 3; k++) R(i, j) += Rb[3 * k + i] * Rw(k, j);
+			}
+		return R;
+	}
+	Eigen::Affine3d transform(const std::string& link_name) const {
+		Eigen::Affine3d T = Eigen::Affine3d::Identity();
+		T.translation() = position(link_name);
+		T.linear() = rotation(link_name);
+		return T;
 	}
 	// world transform of a (possibly fixed-attached) link by its URDF name: forward kinematics on the host, same chain
-	// convention as the library (include/sai2b.h: sai2b_robot_model)
-	Eigen::Affine3d transform(const std::string& link_name) const {
+	// convention as the library (include/sai2b.h: sai2b_robot_model; the base pose is part of the first joint's origin)
+	Eigen::Affine3d transformInWorld(const std::string& link_name) const {
 		const double zero[3] = {0, 0, 0};
 		double fp[3], fr[9];
 		const int link = _impl->resolveLink(link_name, zero, nullptr, fp, fr);

@@ -178,6 +178,14 @@ typedef struct sai2b_urdf_links {
 } sai2b_urdf_links;
 int sai2b_model_from_urdf(const char* urdf, int is_file, sai2b_robot_model* model,
 						  sai2b_urdf_links* links);
+/* Sai2Model::setTRobotBase (examples/05-using_robot_controller/05-using_robot_controller.cpp:69): the pose of the
+ * robot's base in the world. The reference's tasks work in the WORLD frame (MotionForceTask.cpp:100-103,262,
+ * 286-289: positionInWorld / rotationInWorld / JWorldFrame) and the model's gravity is a world vector, so the
+ * transform is folded into the first joint's origin: link -1 of the model is the world afterwards, goals, poses,
+ * forces and Jacobians of a MotionForceTask are world quantities, jointGravityVector sees the rotated base.
+ * Host-only; call it on the model BEFORE sai2b_create() (a context copies the model); a second call composes on
+ * top of the first. rot: row-major rotation matrix, NULL = identity. */
+int sai2b_model_set_base_transform(sai2b_robot_model* model, const double pos[3], const double* rot);
 /* MotionForceTask takes a link NAME and a compliant frame in that link (MotionForceTask.h:96-101,
  * e.g. "end-effector", a body on a fixed joint of link7): resolve them to the moving link index and
  * the frame in it that sai2b_default_motion_force_task() takes. rot_in_link / frame_rot may be NULL. */

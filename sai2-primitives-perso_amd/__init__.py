@@ -24,6 +24,7 @@ from .controller import (  # noqa: F401,E402
     joint_task_config,
     model_from_urdf,
     resolve_link_frame,
+    with_base_transform,
     motion_force_task_config,
     panda_model,
     task_configs,

@@ -172,6 +172,7 @@ EXPORTS = [
     "sai2b_model_merge_fixed_body",
     "sai2b_model_from_urdf",
     "sai2b_urdf_resolve_frame",
+    "sai2b_model_set_base_transform",
     "sai2b_default_joint_task",
     "sai2b_default_joint_task_dof",
     "sai2b_default_motion_force_task",
@@ -256,6 +257,7 @@ def load_library():
     lib.sai2b_model_merge_fixed_body.argtypes = [P(RobotModel), _i, dp, dp, _d, dp, dp]
     lib.sai2b_model_from_urdf.argtypes = [C.c_char_p, _i, P(RobotModel), P(UrdfLinks)]
     lib.sai2b_urdf_resolve_frame.argtypes = [P(UrdfLinks), C.c_char_p, dp, dp, P(_i), dp, dp]
+    lib.sai2b_model_set_base_transform.argtypes = [P(RobotModel), dp, dp]
     lib.sai2b_default_joint_task.argtypes = [P(TaskConfig), C.c_char_p, _i, dp]
     lib.sai2b_default_joint_task_dof.argtypes = [P(TaskConfig), C.c_char_p, _i, _i, dp]
     lib.sai2b_default_motion_force_task_dof.argtypes = [P(TaskConfig), C.c_char_p, _i, _i, dp, dp, _i, dp, _i, dp]

@@ -49,6 +49,19 @@ def model_from_urdf(urdf, is_file=True):
     return m, links
 
 
+def with_base_transform(model, pos, rot=None):
+    """sai2b_model_set_base_transform() on a COPY of the model: Sai2Model::setTRobotBase (examples/05-...cpp:69).
+    The tasks work in the world frame (MotionForceTask.cpp:100-103, 262: positionInWorld / JWorldFrame), so the base
+    pose is part of the model a Controller is built from."""
+    lib = _abi.load_library()
+    m = RobotModel()
+    C.memmove(C.byref(m), C.byref(model), C.sizeof(RobotModel))
+    p = np.ascontiguousarray(pos, dtype=np.float64).reshape(3)
+    r = None if rot is None else np.ascontiguousarray(rot, dtype=np.float64).reshape(9)
+    _check(lib, None, lib.sai2b_model_set_base_transform(C.byref(m), _dp(p), _dp(r)))
+    return m
+
+
 def resolve_link_frame(links, link_name, pos_in_link=(0.0, 0.0, 0.0), rot_in_link=None):
     """sai2b_urdf_resolve_frame(): link name + frame in that link -> (moving link index, frame_pos, frame_rot)"""
     lib = _abi.load_library()

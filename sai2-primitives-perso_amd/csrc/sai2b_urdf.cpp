@@ -470,6 +470,31 @@ extern "C" int sai2b_model_from_urdf(const char* urdf, int is_file, sai2b_robot_
 	return SAI2B_OK;
 }
 
+// Sai2Model::setTRobotBase: T_world_base folded into the first joint's origin (the chain then starts in the world
+// frame, where the tasks work and where the model's gravity vector lives)
+extern "C" int sai2b_model_set_base_transform(sai2b_robot_model* model, const double pos[3], const double* rot) {
+	if (!model || !pos) return fail("sai2b_model_set_base_transform: null argument");
+	if (model->dof < 1 || model->dof > SAI2B_MAX_DOF) return fail("sai2b_model_set_base_transform: the model has no joints");
+	const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+	const double* Rb = rot ? rot : I;
+	double RtR[9];
+	for (int i = 0; i < 3; i++)
+		for (int j = 0; j < 3; j++) RtR[3 * i + j] = Rb[i] * Rb[j] + Rb[3 + i] * Rb[3 + j] + Rb[6 + i] * Rb[6 + j];
+	const double det = Rb[0] * (Rb[4] * Rb[8] - Rb[5] * Rb[7]) - Rb[1] * (Rb[3] * Rb[8] - Rb[5] * Rb[6]) + Rb[2] * (Rb[3] * Rb[7] - Rb[4] * Rb[6]);
+	for (int i = 0; i < 9; i++)
+		if (!(std::fabs(RtR[i] - I[i]) < 1e-9) || !(det > 0) || !std::isfinite(pos[i % 3]))
+			return fail("sai2b_model_set_base_transform: the base orientation is not a rotation matrix (or the position is not finite)");
+	double R0[9], R1[9];
+	sai2b::rot_from_rpy(model->joint_rpy[0], R0);
+	mat_mul(Rb, R0, R1);
+	const double* x = model->joint_xyz[0];
+	const double p1[3] = {pos[0] + Rb[0] * x[0] + Rb[1] * x[1] + Rb[2] * x[2], pos[1] + Rb[3] * x[0] + Rb[4] * x[1] + Rb[5] * x[2],
+						  pos[2] + Rb[6] * x[0] + Rb[7] * x[1] + Rb[8] * x[2]};
+	for (int a = 0; a < 3; a++) model->joint_xyz[0][a] = p1[a];
+	rpy_from_rot(R1, model->joint_rpy[0]);
+	return SAI2B_OK;
+}
+
 // link name + position/orientation in that link -> moving link index + compliant frame in it
 // (MotionForceTask.h:96-101 takes a link name and an Affine3d compliant frame)
 extern "C" int sai2b_urdf_resolve_frame(const sai2b_urdf_links* links, const char* link_name, const double pos_in_link[3],

@@ -4,8 +4,10 @@
 // written for the reference looks like when it only swaps the include. (Eigen itself is not in this image: the test
 // compiles against tests/cpp/mini_eigen, a test double of the handful of Eigen operations used here; with the real
 // Eigen on the include path nothing else changes.) The simulation of the example is Sai2PrimitivesBatched's.
-//   eigen_adapter_test <urdf> <q0 file> <ticks> [manual]   prints, per period: q, dq read from the simulation and the
-//   torques; `manual`: example 04's hand-chained hierarchy instead of the RobotController
+//   eigen_adapter_test <urdf> <q0 file> <ticks> [manual|base]   prints, per period: q, dq read from the simulation and
+//   the torques; `manual`: example 04's hand-chained hierarchy instead of the RobotController; `base`: example 05 with a
+//   robot base away from the world's origin (setTRobotBase)
+#include <cmath>
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -29,6 +31,14 @@ int main(int argc, char** argv) {
 			f.read((char*)buf.data(), buf.size() * sizeof(double));
 			for (int i = 0; i < dof; i++) q0(i) = buf[(size_t)i];
 		}
+		const bool with_base = argc > 4 && string(argv[4]) == "base";
+		if (with_base) {
+			// :69 robot->setTRobotBase(sim->getRobotBaseTransform(robot_name)) — here with a base that is NOT at the
+			// world's origin: goals, poses and Jacobians of the MotionForceTask are world quantities
+			Affine3d T_world_base = Affine3d(Translation3d(Vector3d(0.4, -0.2, 0.35)));
+			T_world_base.linear() = AngleAxisd(0.6, Vector3d(1.0, 2.0, 3.0) * (1.0 / sqrt(14.0))).toRotationMatrix();
+			robot->setTRobotBase(T_world_base);
+		}
 		robot->setQ(q0);	   // :97 (from the simulation's initial state)
 		robot->updateModel();  // :106
 
@@ -43,6 +53,17 @@ int main(int argc, char** argv) {
 		const Matrix3d initial_orientation = robot->rotationInWorld(link_name);
 		const Vector3d initial_position = robot->positionInWorld(link_name, pos_in_link);
 		const VectorXd initial_q = robot->q();
+
+		if (with_base) {  // the plain getters stay in the base frame, the ...InWorld ones include TRobotBase()
+			const Affine3d T = robot->TRobotBase();
+			const Vector3d p_world = T.linear() * robot->position(link_name, pos_in_link) + T.translation();
+			if ((p_world - initial_position).norm() > 1e-12) return 7;
+			const Matrix3d R_world = T.linear() * robot->rotation(link_name);
+			for (int i = 0; i < 3; i++)
+				for (int j = 0; j < 3; j++)
+					if (fabs(R_world(i, j) - initial_orientation(i, j)) > 1e-12) return 7;
+			if ((robot->transformInWorld(link_name).translation() - robot->positionInWorld(link_name)).norm() > 0) return 7;
+		}
 
 		// joint task in the nullspace of the motion-force task (:125-126)
 		auto joint_task = make_shared<Sai2Primitives::JointTask>(robot);

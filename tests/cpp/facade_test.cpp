@@ -118,6 +118,20 @@ static int validate() {
 		m.enableVelocitySaturation(0.25, 0.5);
 		expect(m.getLinearSaturationVelocity() == 0.25 && m.getAngularSaturationVelocity() == 0.5, "saturation velocities");
 	}
+	{	// Sai2Model::setTRobotBase (examples/05-...cpp:69): part of the model the kernels see; a second call replaces the first
+		auto r2 = std::make_shared<BatchedRobotModel>(2);
+		const double c = std::cos(0.3), sn = std::sin(0.3);
+		const double bp[3] = {0.4, -0.2, 0.35}, bR[9] = {c, -sn, 0, sn, c, 0, 0, 0, 1};
+		const double z0 = r2->model().joint_xyz[0][2];
+		r2->setTRobotBase(bp, bR);
+		r2->setTRobotBase(bp, bR);
+		const sai2b_robot_model& mm = r2->model();
+		expect(std::fabs(mm.joint_xyz[0][0] - 0.4) < 1e-15 && std::fabs(mm.joint_xyz[0][2] - (0.35 + z0)) < 1e-15 &&
+				   std::fabs(mm.joint_rpy[0][2] - 0.3) < 1e-15 && r2->TRobotBasePosition()[1] == -0.2 && r2->TRobotBaseRotation()[1] == -sn,
+			   "base pose folded into the first joint");
+		const double mirror[9] = {1, 0, 0, 0, 1, 0, 0, 0, -1};
+		expect(throws_invalid([&] { r2->setTRobotBase(bp, mirror); }, "not a rotation matrix"), "reflection as base orientation");
+	}
 	std::printf(fails ? "validate: %d failures\n" : "validate: ok\n", fails);
 	return fails;
 }

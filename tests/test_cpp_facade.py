@@ -801,10 +801,12 @@ def test_eigen_adapter_compiles(eigen_bin):
 
 
 @pytest.mark.gpu
-def test_eigen_adapter_runs_example_05_with_the_references_own_types(eigen_bin, tmp_path):
+@pytest.mark.parametrize("base", [False, True])
+def test_eigen_adapter_runs_example_05_with_the_references_own_types(eigen_bin, tmp_path, base):
     """include/Sai2PrimitivesEigen.h: the reference's signatures (shared_ptr<Sai2Model::Sai2Model>, Affine3d, Vector3d,
     Matrix3d, VectorXd) for one robot. tests/cpp/eigen_adapter_test.cpp is example 05 as a reference user wrote it; its
-    torques against the oracle, period by period."""
+    torques against the oracle, period by period. base: with robot->setTRobotBase(T) (05-...cpp:69) for a base that is
+    away from the world's origin — the MotionForceTask's poses and goals are then world quantities."""
     import oracle_lib as ol
     from test_urdf import _urdf_from_model
 
@@ -814,10 +816,14 @@ def test_eigen_adapter_runs_example_05_with_the_references_own_types(eigen_bin, 
     q0 = pkg.workloads.make_inputs(3, B=4, seed=55)["q"][:, :1].copy()
     path = tmp_path / "q.bin"
     np.ascontiguousarray(q0[:, 0]).tofile(path)
-    r = subprocess.run([eigen_bin, str(urdf), str(path), str(ticks)], capture_output=True)
+    r = subprocess.run([eigen_bin, str(urdf), str(path), str(ticks)] + (["base"] if base else []), capture_output=True)
     assert r.returncode == 0, (r.returncode, r.stderr.decode())
     out = np.frombuffer(r.stdout, dtype=np.float64).reshape(ticks, 3, 7, 1)
     m, links = pkg.model_from_urdf(str(urdf))
+    if base:
+        a = np.array([1.0, 2.0, 3.0]) / np.sqrt(14.0)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        m = pkg.with_base_transform(m, (0.4, -0.2, 0.35), np.eye(3) + np.sin(0.6) * K + (1 - np.cos(0.6)) * K @ K)
     link, fpos, frot = pkg.resolve_link_frame(links, "end-effector", (0.0, 0.0, 0.07))
     o = ol.Oracle(m, [ol.motion_force_task("motion_force_task", link, fpos, frot), ol.joint_task("joint_task", internal_otg=True)], 1)
     o.set_state(q0, np.zeros_like(q0))

@@ -728,3 +728,46 @@ def test_split_calls_run_the_fused_tick_and_flush_when_observed():
     tau_o, tau_g = o.compute_control_torques(True), g.compute_control_torques(True)
     e = _err(tau_g, tau_o)
     assert e[ro == 6].max() < 1e-9 and e.max() < 1e-5
+
+
+def test_robot_base_away_from_the_world_origin():
+    """Sai2Model::setTRobotBase (examples/05-using_robot_controller.cpp:69) = sai2b_model_set_base_transform: poses,
+    goals and Jacobians of a MotionForceTask are WORLD quantities (MotionForceTask.cpp:100-103, 262). (1) a Panda on a
+    shifted and tilted base against the oracle, SVD-free and generic kernels, gravity compensation on (g(q) sees the
+    tilt); (2) a property no restatement shares: the law is covariant — the same robot at the world's origin, with
+    the goals carried back into its base frame, must produce the same torques (gravity off)."""
+    B = 1024 + 5
+    inp = pkg.workloads.make_inputs(3, B=B, seed=91)
+    a = np.array([2.0, -1.0, 0.5]) / np.sqrt(5.25)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    Rb, pb = np.eye(3) + np.sin(0.8) * K + (1 - np.cos(0.8)) * K @ K, np.array([0.4, -0.2, 0.35])
+    moved = pkg.with_base_transform(pkg.panda_model(), pb, Rb)
+    world = {k: (dict(v) if isinstance(v, dict) else v) for k, v in inp.items()}
+    g0 = world["mft0"]
+    g0["pos"] = pb[:, None] + Rb @ inp["mft0"]["pos"]
+    g0["rot"] = np.ascontiguousarray(np.einsum("ik,kjb->ijb", Rb, inp["mft0"]["rot"].reshape(3, 3, B)).reshape(9, B))
+    for k in ("v", "w", "a", "alpha"):
+        g0[k] = Rb @ inp["mft0"][k]
+    at_origin = pkg.Controller(pkg.panda_model(), pkg.task_configs(inp["tasks"]), B)
+    ol.load_inputs(at_origin, inp)
+    tau_origin = at_origin.tick()
+    for introspection in (False, True):
+        o = ol.Oracle(moved, ol.task_configs(inp["tasks"]), B, threads=8)
+        g = pkg.Controller(moved, pkg.task_configs(inp["tasks"]), B, introspection=introspection)
+        ol.load_inputs(o, world)
+        ol.load_inputs(g, world)
+        tau_o, tau_g = o.tick(), g.tick()
+        _, _, ro = o.get_mft_singularity(0)
+        regular = ro == 6
+        assert _err(tau_g, tau_o)[regular].max() < 10 * TOL and _err(tau_g, tau_o).max() < 1e-6
+        st = g.get_mft_status(0)
+        st0 = at_origin.get_mft_status(0)
+        assert np.abs(st["pos"] - (pb[:, None] + Rb @ st0["pos"])).max() < 1e-13
+        e = _err(tau_g, tau_origin)
+        assert e[regular].max() < 1e-9, e[regular].max()  # covariance
+        assert e.max() < 1e-5
+        for c in (o, g):
+            c.enable_gravity_compensation(True)
+        tau_o, tau_g = o.tick(), g.tick()
+        assert _err(tau_g, tau_o)[regular].max() < 10 * TOL
+        assert np.abs(tau_g - tau_origin).max() > 1.0  # the tilted base's gravity torques are in there
