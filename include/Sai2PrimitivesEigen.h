@@ -240,6 +240,17 @@ using B_::PIDGains;
 using B_::TaskType;
 using B_::UNDEFINED;
 
+// reference src/helper_modules/Sai2PrimitivesCommonDefinitions.h:25-27: one field of a gain list as a vector
+template <class Field>
+inline VectorXd gainFieldAsVector_(const vector<PIDGains>& gains, Field field) {
+	VectorXd out((int)gains.size());
+	for (size_t i = 0; i < gains.size(); i++) out((int)i) = field(gains[i]);
+	return out;
+}
+inline VectorXd extractKpFromGainVector(const vector<PIDGains>& gains) { return gainFieldAsVector_(gains, [](const PIDGains& g) { return g.kp; }); }
+inline VectorXd extractKvFromGainVector(const vector<PIDGains>& gains) { return gainFieldAsVector_(gains, [](const PIDGains& g) { return g.kv; }); }
+inline VectorXd extractKiFromGainVector(const vector<PIDGains>& gains) { return gainFieldAsVector_(gains, [](const PIDGains& g) { return g.ki; }); }
+
 // reference src/tasks/TemplateTask.h:25-123
 class TemplateTask {
 public:

@@ -1,0 +1,4 @@
+// tasks/TemplateTask.h — forwarding header: lets a program written against the reference's headers (src/tasks/TemplateTask.h) compile with
+// only the include path changed (-I <repo>/include/sai2_compat). Everything is declared in Sai2PrimitivesEigen.h.
+#pragma once
+#include "../../Sai2PrimitivesEigen.h"

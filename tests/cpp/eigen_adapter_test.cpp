@@ -12,7 +12,11 @@
 #include <fstream>
 #include <iostream>
 
-#include "Sai2PrimitivesEigen.h"
+// the reference example's own include lines (05-using_robot_controller.cpp:8-13), resolved by include/sai2_compat
+#include "RobotController.h"
+#include "Sai2Model.h"
+#include "tasks/JointTask.h"
+#include "tasks/MotionForceTask.h"
 
 using namespace std;
 using namespace Eigen;
@@ -151,6 +155,11 @@ int main(int argc, char** argv) {
 			fwrite(out.data(), sizeof(double), out.size(), stdout);
 			sim.integrate();
 		}
+		// Sai2PrimitivesCommonDefinitions.h:25-27
+		const VectorXd kp = Sai2Primitives::extractKpFromGainVector(joint_task->getGains());
+		if (kp.size() != 1 || kp(0) != 50.0 || Sai2Primitives::extractKvFromGainVector(joint_task->getGains())(0) != 14.0 ||
+			Sai2Primitives::extractKiFromGainVector(joint_task->getGains())(0) != 0.0)
+			return 8;
 		// a few of the reference's getters, Eigen-typed
 		if ((motion_force_task->getGoalPosition() - motion_force_task->getCurrentPosition()).norm() > 0.2) return 5;
 		if (joint_task->getGoalPosition().size() != dof || motion_force_task->getTaskAndPreviousNullspace().rows() != dof) return 6;

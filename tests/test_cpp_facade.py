@@ -788,7 +788,7 @@ def eigen_bin(tmp_path_factory):
     pkg._abi.load_library()
     out = str(tmp_path_factory.mktemp("cpp") / "eigen_adapter_test")
     subprocess.run(
-        ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "cpp", "mini_eigen"),
+        ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include", "sai2_compat"), "-I", os.path.join(ROOT, "tests", "cpp", "mini_eigen"),
          os.path.join(ROOT, "tests", "cpp", "eigen_adapter_test.cpp"), "-o", out, "-L", CSRC, "-lsai2b", f"-Wl,-rpath,{CSRC}",
          "-Wl,-rpath,/opt/rocm/lib"],
         check=True,
