@@ -121,7 +121,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="robots per GPU (default: the config's size; 65536 for C3)")
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--backend", default="gloo",
+                    help="torch.distributed backend of the timing protocol for N > 1 (a barrier and a MAX of four scalars: "
+                         "the path has no exchange step, so no RCCL communicator is set up by default; nccl = RCCL)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 

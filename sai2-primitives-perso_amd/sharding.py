@@ -1,7 +1,8 @@
 """Multi-GPU bookkeeping: robots are independent, so a node run shards the batch —
 one process per GPU, contiguous shards generated per rank, NO collective on the data path. The only
 communication is the timing protocol of bench.py: a barrier and a MAX-reduction of two scalars.
-backend "nccl" (= RCCL) on GPUs, "gloo" in the CPU tests."""
+Both go over "gloo" by default, on GPUs too: with no exchange step on the path there is nothing for an RCCL
+communicator to carry, and the timing protocol should not depend on one coming up ("nccl" = RCCL can be asked for)."""
 import os
 
 import torch
