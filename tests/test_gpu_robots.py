@@ -4,6 +4,8 @@ the slider and the last joint, MotionForceTask, full JointTask]) and the planar 
 of examples/11-planar_robot_controller/11-planar_robot_controller.cpp:108-125 (+ JointTask), against the CPU oracle
 built for that robot size. The models themselves are pinned against an independent numpy reading of the URDFs in
 tests/test_urdf.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -78,14 +80,17 @@ def _setup(robot, B, otg, introspection, seed=0):
     return m, kinds, o, g, q, dq
 
 
+# SAI2B_ROBOT_SEEDS=<n> widens the sweep (300 seeds of every combination were run clean when this was written)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SAI2B_ROBOT_SEEDS", "1"))))
 @pytest.mark.parametrize("introspection", [True, False])
 @pytest.mark.parametrize("otg", [False, True])
 @pytest.mark.parametrize("robot", list(robots.TEXT))
-def test_other_robots_match_the_oracle_in_closed_loop(robot, otg, introspection):
+def test_other_robots_match_the_oracle_in_closed_loop(robot, otg, introspection, seed):
     """10 control periods through the simulation harness: torques every period, joint states at the end;
-    introspection on = the one-lane-per-robot kernels, off = the lanes-per-robot generic kernel"""
+    introspection on = the one-lane-per-robot kernels, off = the SVD-free kernel for general hierarchies with the
+    lanes-per-robot generic kernel behind it"""
     B = 192
-    m, kinds, o, g, q, dq = _setup(robot, B, otg, introspection)
+    m, kinds, o, g, q, dq = _setup(robot, B, otg, introspection, seed=seed)
     n = m.dof
     if introspection:
         g.tick(), o.tick()
@@ -94,17 +99,22 @@ def test_other_robots_match_the_oracle_in_closed_loop(robot, otg, introspection)
         tau_o, tau_g = o.tick(), g.tick()
         assert tau_g.shape == (n, B)
         singular = np.zeros(B, dtype=bool)
+        tol_singular = np.full(B, 1e-5)
         for t, k in enumerate(kinds):
             if k == "mft":
-                _, _, ro = o.get_mft_singularity(t)
-                singular |= ro < (o.tasks[t].pos_range + o.tasks[t].ori_range)
+                sig, _, ro = o.get_mft_singularity(t)
+                rank = o.tasks[t].pos_range + o.tasks[t].ori_range
+                singular |= ro < rank
+                # the reference inverts J_s M^-1 J_s^T as it is (SingularityHandler.cpp:120): rounding is amplified by
+                # (s_0 / s_min)^2. Seen in the 300-seed sweep: a robot crossing s_5 = 2e-6 (s_0 = 2.1), 2.4e-5
+                tol_singular = np.maximum(tol_singular, 1e-16 * (sig[0] / np.maximum(sig[rank - 1], 1e-12)) ** 2)
                 # a robot whose condition number sits on the blending threshold within rounding may be inside the
                 # region on one side only (seen: 1 of 192 six_r robots, one period): either side's word counts
                 singular |= g.get_singularity_types_count(t) > 0
         e = _err(tau_g, tau_o)
         assert e[~singular].max() < 1e-9, (period, e[~singular].max())
         if singular.any():
-            assert e[singular].max() < 1e-5
+            assert (e[singular] < np.minimum(tol_singular[singular], 1e-2)).all(), e[singular].max()
         for c in (o, g):
             c.sim_step(tau_o, 0.001, 1, with_gravity=False)
     qo, vo = o.get_state()
