@@ -46,13 +46,13 @@ def apply_opts(cfg, opts):
             if cfg.type == pkg.MOTION_FORCE_TASK:
                 cfg.linear_saturation_velocity, cfg.angular_saturation_velocity = v
             else:
-                for i in range(pkg.DOF):
+                for i in range(len(cfg.saturation_velocity)):  # every slot: robots of up to SAI2B_MAX_DOF joints
                     cfg.saturation_velocity[i] = v
         elif k in ("kp_pos", "kv_pos", "ki_pos", "kp_ori", "kv_ori", "ki_ori"):
             for i in range(3):
                 getattr(cfg, k)[i] = v
         elif k in ("kp", "kv", "ki"):
-            for i in range(pkg.DOF):
+            for i in range(len(getattr(cfg, k))):
                 getattr(cfg, k)[i] = v
         elif k in ("force_space_dimension", "moment_space_dimension"):
             setattr(cfg, k, v)
