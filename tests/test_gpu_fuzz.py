@@ -386,3 +386,68 @@ def test_random_runtime_events_closed_loop(seed):
             if mask.any():
                 assert np.abs(qg - qo)[:, mask].max() < tq and np.abs(dqg - dqo)[:, mask].max() < tdq, (ctx, "state")
         g.set_state(qo, dqo)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SAI2B_FUZZ_SEEDS", "16"))))
+def test_random_hierarchy_through_the_task_level_calls(seed):
+    """The TemplateTask virtuals (TemplateTask.h:42-88) on a random hierarchy with random options, the caller chaining
+    the nullspaces (examples/04-task_and_redundancy.cpp:141-150, 188-206): updateTaskModel(N_prec) down the list, then
+    computeTorques() or computeTorques(tau_prec) accumulated in priority order — every task's nullspaces and torques
+    against the oracle's same calls, four periods closed through the simulation harness (one step apart: the GPU side
+    continues from the oracle's state, so an unstable draw of gains cannot amplify rounding)."""
+    rng = np.random.default_rng(11000 + seed)
+    name = sorted(SHAPES)[seed % len(SHAPES)]
+    tasks = SHAPES[name]
+    B = int(rng.integers(70, 200))
+    inp = _custom_inputs(tasks, B, seed=zlib.crc32(name.encode()) % 1000 + 500 + seed, singular_fraction=0.1)
+    opts = _draw_opts(rng, tasks)
+    for op in opts:
+        op.pop("passivity", None)  # the observer's counters advance per computeTorques call: kept to the controller-level fuzz
+    otg = bool(rng.integers(2))
+    with_prec = bool(rng.integers(2))
+    o = ol.Oracle(ol.panda_model(), _configs(ol.task_configs, tasks, opts, otg), B, threads=8)
+    g = pkg.Controller(pkg.panda_model(), _configs(pkg.task_configs, tasks, opts, otg), B)
+    wrench = {k: rng.normal(0, s, size=(3, B)) for k, s in (("f", 3.0), ("m", 0.5), ("sf", 3.0), ("sm", 0.5))}
+    for c in (o, g):
+        ol.load_inputs(c, inp)
+        c.reinitialize()
+        ol.load_inputs(c, inp)
+        for t, (kind, _) in enumerate(tasks):
+            if kind == "mft" and "force_space_dimension" in opts[t]:
+                c.set_mft_goal_wrench(t, wrench["f"], wrench["m"])
+                c.set_mft_sensed_wrench(t, wrench["sf"], wrench["sm"])
+    what = (seed, name, opts, otg, with_prec, B)
+    for period in range(4):
+        out = []
+        for c in (o, g):
+            N_prec, per_task = None, []
+            for t in range(len(tasks)):
+                c.task_update_model(t, N_prec)
+                per_task.append(c.task_nullspaces(t))
+                N_prec = per_task[-1][2]
+            tau, taus = np.zeros((N, B)), []
+            for t in range(len(tasks)):
+                taus.append(c.task_compute_torques(t, tau) if with_prec else c.task_compute_torques(t))
+                tau = tau + taus[-1]
+            out.append((per_task, taus, tau))
+        (no, to, tau_o), (ng, tg, tau_g) = out
+        regular = np.ones(B, dtype=bool)
+        for t, (kind, _) in enumerate(tasks):
+            if kind == "mft":
+                _, _, ro = o.get_mft_singularity(t)
+                regular &= ro == (o.tasks[t].pos_range + o.tasks[t].ori_range)
+        for t in range(len(tasks)):
+            for a, b in zip(ng[t], no[t]):
+                d = np.abs(a - b).max(axis=0)
+                assert d[regular].max() < 1e-8, (what, period, t, float(d[regular].max()))
+            den = np.maximum(np.abs(tau_o).max(axis=0), 1e-9)
+            e = np.abs(tg[t] - to[t]).max(axis=0) / den
+            assert e[regular].max() < 1e-8, (what, period, t, float(e[regular].max()))
+            if (~regular).any():
+                assert e[~regular].max() < 1e-5, (what, period, t, float(e[~regular].max()))
+        o.sim_step(tau_o, 0.001, 1)
+        g.sim_step(tau_o, 0.001, 1)
+        qo, dqo = o.get_state()
+        qg, dqg = g.get_state()
+        assert np.abs(qg - qo).max() < 1e-12 * max(1.0, np.abs(qo).max()) and np.abs(dqg - dqo).max() < 1e-9 * max(1.0, np.abs(dqo).max()), what
+        g.set_state(qo, dqo)
