@@ -448,6 +448,20 @@ class BatchedRobotModel:
     def dof(self):
         return int(self.model.dof)
 
+    def setTRobotBase(self, pos, rot=None):
+        """Sai2Model::setTRobotBase (examples/05-using_robot_controller.cpp:69): the robot base in the world; replaces an
+        earlier one. Part of the model the kernels see (with_base_transform): before a controller or a task runs on it."""
+        if self._controller is not None or self._standalone:
+            raise ValueError("setTRobotBase must be called before a controller or a task runs on this robot model")
+        if not hasattr(self, "_model_in_base"):
+            self._model_in_base = self.model
+        self.model = with_base_transform(self._model_in_base, pos, rot)
+        self._base = (np.array(pos, dtype=np.float64).reshape(3), np.eye(3) if rot is None else np.array(rot, dtype=np.float64).reshape(3, 3))
+
+    def TRobotBase(self):
+        """(position, rotation) of the base in the world"""
+        return getattr(self, "_base", (np.zeros(3), np.eye(3)))
+
     def setQ(self, q):
         self._q = q
         self._push()
