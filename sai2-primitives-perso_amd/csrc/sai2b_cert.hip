@@ -39,6 +39,27 @@ __global__ __launch_bounds__(64) void tick_cert_kernel(const DevParams* __restri
 	UNROLL for (int i = 0; i < N; i++) st(P.tau, i, B, b, tau[i] + pend[i * 64]);  // RobotController.cpp:70-72
 }
 
+// The range pass ahead of the trajectory generators (cert::range_tick): OTG_ACTIVE of the gated JointTasks for the
+// robots whose levels are all certified; the others go to a work list for the generic kernel's range pass, with
+// the same two alternating counters protocol as above.
+template <int MCAP>
+__global__ __launch_bounds__(64) void range_cert_kernel(const DevParams* __restrict__ Pp, int* __restrict__ rg_counts, int* __restrict__ rg_list,
+													   int parity) {
+	const DevParams& P = *Pp;
+	const int B = P.B;
+	const int b = blockIdx.x * 64 + threadIdx.x;
+	if (blockIdx.x == 0 && threadIdx.x == 0) ((gint*)rg_counts)[1 - parity] = 0;
+	if (b >= B) return;
+	const bool mine = cert::range_tick<MCAP>(P, P.model, B, b);
+	const unsigned long long declined = __ballot(!mine);
+	if (declined) {
+		int base = 0;
+		if (threadIdx.x == 0) base = atomicAdd(&rg_counts[parity], __popcll(declined));  // lane 0 is always in range
+		base = __shfl(base, 0);
+		if (!mine) ((gint*)rg_list)[base + __popcll(declined & ((1ull << threadIdx.x) - 1ull))] = b;
+	}
+}
+
 }  // namespace sai2b
 
 #ifdef SAI2B_CERT_STAMP
@@ -55,6 +76,16 @@ extern "C" int sai2b_debug_read_cstamps(unsigned long long* out, int cap) {
 	return n;
 }
 #endif
+
+extern "C" int sai2b_launch_range_cert(const sai2b::DevParams* d_params, int B, int max_rows, int* rg_counts, int* rg_list, int parity,
+									   hipStream_t stream) {
+	const dim3 grid((B + 63) / 64), block(64);
+	if (max_rows <= 3)
+		hipLaunchKernelGGL(sai2b::range_cert_kernel<3>, grid, block, 0, stream, d_params, rg_counts, rg_list, parity);
+	else
+		hipLaunchKernelGGL(sai2b::range_cert_kernel<6>, grid, block, 0, stream, d_params, rg_counts, rg_list, parity);
+	return (int)hipGetLastError();
+}
 
 extern "C" int sai2b_launch_tick_cert(const sai2b::DevParams* d_params, int B, int max_rows, int with_comp, int* fb_counts, int* fb_list,
 									  int parity, hipStream_t stream) {

@@ -122,7 +122,8 @@ DI bool certify_gram_lower(const real* G, real abs2, real rel2) {
 // Order of the phases keeps few matrices alive: Y, Jp -> certificate -> the torque terms that need Jp (direct and
 // bounded-inertia ones: Jp^T x = LB (YB x), YB = LB^-1 Jp^T overwrites Jp) -> Gram-Schmidt of Y ->
 // Lambda term as L (Z R^-T a) -> downdate of Q.
-template <int M>
+// TORQUE = false: the cascade alone (certificate and Q), for the range pass ahead of the trajectory generators.
+template <int M, bool TORQUE = true>
 DI bool level(const Fact& f, const real* Jr, bool first, bool last, bool do_cert, real abs2, real rel2, int decoupling,
 			  bool has_va, const real* va, const real* vf, const real* vd, real* Q, real* tau) {
 	real Y[M * N], JP[M * N];
@@ -163,14 +164,14 @@ DI bool level(const Fact& f, const real* Jr, bool first, bool last, bool do_cert
 	SAI2B_PHASE();
 	CSTAMP(21);
 	const bool full = decoupling == SAI2B_FULL_DYNAMIC_DECOUPLING;
-	{  // direct terms: Jp^T (vd (+ vf with IMPEDANCE: Lambda_mod = projector onto the range))
+	if constexpr (TORQUE) {	 // direct terms: Jp^T (vd (+ vf with IMPEDANCE: Lambda_mod = projector onto the range))
 		const bool imp = decoupling == SAI2B_IMPEDANCE;
 		UNROLL for (int c = 0; c < M; c++) {
 			const real zc = vd[c] + (imp ? vf[c] : 0.0);
 			UNROLL for (int i = 0; i < N; i++) tau[i] = fma(JP[c * N + i], zc, tau[i]);
 		}
 	}
-	if (decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES) {
+	if (TORQUE && decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES) {
 		// Lambda_mod = (Jp M_BIE^-1 Jp^T)^-1 = (YB^T YB)^-1, YB = LB^-1 Jp^T; torques Jp^T x = LB (YB x)
 		// LB comes from LDS a row at a time (each row serves all M columns): it is never whole in registers
 		UNROLL for (int i = 0; i < N; i++) {
@@ -222,7 +223,7 @@ DI bool level(const Fact& f, const real* Jr, bool first, bool last, bool do_cert
 			UNROLL for (int i = 0; i < N; i++) Y[k * N + i] = fma(-s, Y[j * N + i], Y[k * N + i]);
 		}
 	}
-	if (has_va || full) {  // Jp^T Lambda a = L Y R^-1 R^-T a = L Z (R^-T a)
+	if (TORQUE && (has_va || full)) {  // Jp^T Lambda a = L Y R^-1 R^-T a = L Z (R^-T a)
 		real u[M], w[N];
 		UNROLL for (int j = 0; j < M; j++) {
 			real t = (has_va ? va[j] : 0.0) + (full ? vf[j] : 0.0);
@@ -249,13 +250,13 @@ DI bool level(const Fact& f, const real* Jr, bool first, bool last, bool do_cert
 	return ok;
 }
 // run-time row count (the same for every robot) -> the instantiation
-template <int M>
+template <int M, bool TORQUE = true>
 DI bool level_any(int m, const Fact& f, const real* Jr, bool first, bool last, bool do_cert, real abs2, real rel2, int decoupling,
 				  bool has_va, const real* va, const real* vf, const real* vd, real* Q, real* tau) {
 	if constexpr (M > 1) {
-		if (m < M) return level_any<M - 1>(m, f, Jr, first, last, do_cert, abs2, rel2, decoupling, has_va, va, vf, vd, Q, tau);
+		if (m < M) return level_any<M - 1, TORQUE>(m, f, Jr, first, last, do_cert, abs2, rel2, decoupling, has_va, va, vf, vd, Q, tau);
 	}
-	return level<M>(f, Jr, first, last, do_cert, abs2, rel2, decoupling, has_va, va, vf, vd, Q, tau);
+	return level<M, TORQUE>(f, Jr, first, last, do_cert, abs2, rel2, decoupling, has_va, va, vf, vd, Q, tau);
 }
 
 // A full JointTask behind other tasks: Jp = N_prec = L^-T Q L^T with rank D = n - (rows of the certified tasks
@@ -666,6 +667,84 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 		}
 		if (wrows > N) wrows = N;
 		CSTAMP(40);
+	}
+	return ok;
+}
+
+// The range pass ahead of the trajectory generators for the robots this kernel family can vouch for: a JointTask whose
+// range can come out empty leaves its generator alone on such a tick (JointTask.cpp:233-239, 302-306), so the generator
+// kernels need "active this tick" per robot before the tick itself runs (DevTask::otg_gated, row OTG_ACTIVE). The model
+// and the cascade of tick() without laws, torques or stores, down to the last gated task: a partial JointTask whose
+// level carries its certificate has all its rows in its range (active); a full one at the bottom is active while
+// rows are left. Returns false when some level could not be certified: the caller hands the robot to the range pass
+// of the generic kernel, which decides (and overwrites) with the reference's own rule.
+template <int MCAP, class MD>
+DI bool range_tick(const DevParams& P, const MD& md, int B, int b) {
+	Fact f;
+	f.lb = nullptr;
+	real q[N];
+	UNROLL for (int i = 0; i < N; i++) q[i] = ld(P.q, i, B, b);
+	{
+		Frames F;
+		fk(md, q, F);
+		real M[N * N];
+		mass_matrix(md, F, M);
+		SAI2B_PHASE();
+		chol<N>(M, f.L, f.dL);
+	}
+	SAI2B_PHASE();
+	real Q[N * N], tau[N];
+	UNROLL for (int i = 0; i < N * N; i++) Q[i] = (i % (N + 1) == 0) ? 1.0 : 0.0;
+	UNROLL for (int i = 0; i < N; i++) tau[i] = 0;
+	int n_run = 0;
+	for (int ti = 0; ti < P.n_tasks; ti++)
+		if (P.task[ti].otg_gated) n_run = ti + 1;
+	bool ok = true;
+	int wrows = 0;
+	const real zero[N] = {};
+#pragma unroll 1
+	for (int ti = 0; ti < n_run; ti++) {
+		const DevTask& t = P.task[ti];
+		const bool first = (ti == 0), last = (ti == n_run - 1);
+		if (t.type == SAI2B_MOTION_FORCE_TASK) {
+			const int n_types = ldi(t.istate, IS_NTYPES, B, b);
+			real Jw[6 * N];
+			{
+				real sc[2 * N], x[3], R[9];
+				UNROLL for (int i = 0; i < N; i++) {
+					real s_, c_;
+					sincos_joint(q[i], &s_, &c_);
+					const bool pris = md.jtype[i] != 0;
+					sc[2 * i] = pris ? 0.0 : s_, sc[2 * i + 1] = pris ? 1.0 : c_;
+				}
+				jacobian_and_pose(md, t, q, sc, Jw, x, R);
+			}
+			const int m = t.rank;
+			if (wrows + m > N) ok = false;
+			const real abs2 = t.s_abs_tol * t.s_abs_tol, rel2 = t.s_max * t.s_max;
+			bool c_ok;
+			if (t.full_projection || t.p_lead < 6) {
+				c_ok = level_any<(MCAP < 6 ? MCAP : 6), false>(m, f, Jw, first, last, true, abs2, rel2, t.decoupling, false, zero, zero, zero, Q, tau);
+			} else {
+				real Jr[6 * N];
+				mm_tn<6, 6, N>(t.PU, Jw, Jr);
+				c_ok = level_any<(MCAP < 6 ? MCAP : 6), false>(m, f, Jr, first, last, true, abs2, rel2, t.decoupling, false, zero, zero, zero, Q, tau);
+			}
+			ok = ok & c_ok & (n_types == 0);
+			wrows += m;
+		} else if (t.full_selection) {
+			if (t.otg_gated) st(t.otg_state, OTG_ACTIVE, B, b, wrows < N ? 1.0 : 0.0);
+			UNROLL for (int i = 0; i < N * N; i++) Q[i] = 0;
+			wrows = N;
+		} else {
+			const int k0 = t.k0;
+			if (wrows + k0 > N) ok = false;
+			const bool c_ok = level_any<(MCAP < N ? MCAP : N), false>(k0, f, t.S, first, last, !first, 1e-6, 1e-6, t.decoupling, false, zero, zero, zero, Q, tau);
+			ok = ok & c_ok;
+			if (t.otg_gated) st(t.otg_state, OTG_ACTIVE, B, b, 1.0);
+			wrows += k0;
+		}
+		if (wrows > N) wrows = N;
 	}
 	return ok;
 }

@@ -44,6 +44,9 @@ struct sai2b_ctx {
 	int generic_lanes_env = 0;
 	int* fb_counts = nullptr;	// [2] robots the SVD-free kernel handed to the generic one (alternating by fb_parity)
 	int* fb_list = nullptr;		// [B] their indices
+	int* rg_counts = nullptr;	// [2], rg_list [B]: the same for the range pass ahead of the trajectory generators
+	int* rg_list = nullptr;
+	int rg_parity = 0;
 	int fb_parity = 0;			// counter set of the last SVD-free launch
 	// How many robots the SVD-free kernel for general hierarchies keeps is a property of the workload (a 6-DOF task
 	// behind a partial JointTask is inside a blending region most of the time): every 8th such tick its count of
@@ -663,6 +666,8 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	if ((rc = dev_alloc(ctx, &ctx->q_pose, (size_t)N * Bs))) return rc;
 	if ((rc = dev_alloc(ctx, &ctx->fb_counts, 2))) return rc;
 	if ((rc = dev_alloc(ctx, &ctx->fb_list, Bs))) return rc;
+	if ((rc = dev_alloc(ctx, &ctx->rg_counts, 2))) return rc;
+	if ((rc = dev_alloc(ctx, &ctx->rg_list, Bs))) return rc;
 	HIP_TRY(ctx, hipHostMalloc((void**)&ctx->fb_seen, sizeof(int), hipHostMallocDefault));
 	HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fb_seen_ev, hipEventDisableTiming));
 	if ((rc = dev_alloc(ctx, &ctx->otg_counts, 2 * SAI2B_MAX_TASKS))) return rc;
@@ -1045,10 +1050,21 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 	if (rc) return rc;
 	const int fast = fast_kind(ctx);
 	if (do_torque && gated) {
-		// which robots' gated tasks are active this tick: the task models of the current state, nothing committed
-		if (sai2b_launch_range_pass(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, with_comp, generic_lanes(ctx, true), ctx->stream))
-			return set_error(ctx, SAI2B_RUNTIME_ERROR, "task-range pass launch failed");
-		ctx->launches++;
+		// which robots' gated tasks are active this tick: the task models of the current state, nothing committed.
+		// Where the SVD-free kernel for general hierarchies applies (and keeps most of the batch), its cascade decides
+		// for the robots it can certify and only the others take the generic kernel's range pass
+		const int ck = (ctx->introspection || ctx->cert_backoff > 0) ? 0 : cert_kind(ctx);
+		if (ck) {
+			if (sai2b_launch_range_cert(ctx->d_params, ctx->B, ck - 3, ctx->rg_counts, ctx->rg_list, ctx->rg_parity, ctx->stream) ||
+				sai2b_launch_tick_group(ctx->d_params, ctx->B, 16, 1, 0, with_comp, 0, ctx->rg_counts + ctx->rg_parity, ctx->rg_list, ctx->stream))
+				return set_error(ctx, SAI2B_RUNTIME_ERROR, "task-range pass launch failed");
+			ctx->rg_parity ^= 1;
+			ctx->launches += 2;
+		} else {
+			if (sai2b_launch_range_pass(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, with_comp, generic_lanes(ctx, true), ctx->stream))
+				return set_error(ctx, SAI2B_RUNTIME_ERROR, "task-range pass launch failed");
+			ctx->launches++;
+		}
 	}
 	if (do_torque && any_otg(ctx)) {  // the generators advance once per torque computation, before the law
 		// (a gated task keeps reading its goals: a robot skipped while they changed must see them later)

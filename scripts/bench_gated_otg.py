@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """C4 hierarchy [MFT(3), JT(2), JT(7)] with the tasks' internal OTG off / on. With it on, the 2-joint task's
-generator is gated per robot (its range can be empty: DESIGN.md 8b), which costs a model-only pass of the
-generic kernel ahead of the generator kernels."""
+generator is gated per robot (its range can be empty: DESIGN.md 8b), which costs a model-only pass ahead of the
+generator kernels: the SVD-free cascade for the robots it can certify, the generic kernel for the others
+(SAI2B_NO_CERT_PATH=1: the generic kernel for the whole batch, as before round 2's range_cert_kernel)."""
 import os
 import sys
 import time

@@ -333,8 +333,11 @@ def test_gpu_otg_reinitialize_mid_motion_ragged_batch():
         assert np.array_equal(a, b_)
 
 
-def test_gpu_otg_of_task_with_empty_range_waits_like_the_reference():
-    """[MFT(6), JT(1 joint), JT(7)]: on a regular robot the last task has no degree of freedom left, and the
+@pytest.mark.parametrize("introspection", [True, False])
+def test_gpu_otg_of_task_with_empty_range_waits_like_the_reference(introspection):
+    """(introspection off: the range pass ahead of the generators is the SVD-free cascade for the robots it can
+    certify — sai2b_cert.hpp: range_tick — and the generic kernel's for the others, here the singular half.)
+    [MFT(6), JT(1 joint), JT(7)]: on a regular robot the last task has no degree of freedom left, and the
     reference then returns before it touches the task's generator (JointTask.cpp:302-306), so the
     generator waits — time, state and pending goal changes — until the task has a range again (here: when
     the robot is moved into the 6-DOF task's singular region, whose handling strategy is off so that the
@@ -350,7 +353,7 @@ def test_gpu_otg_of_task_with_empty_range_waits_like_the_reference():
           pkg.joint_task_config("j7", internal_otg=True)]
     to[0].enforce_handling_strategy = tg[0].enforce_handling_strategy = 0
     o = ol.Oracle(ol.panda_model(), to, B, threads=8)
-    g = pkg.Controller(pkg.panda_model(), tg, B, introspection=True)
+    g = pkg.Controller(pkg.panda_model(), tg, B, introspection=introspection)
     q_reg = inp["q"].copy()
     q_sing = q_reg.copy()
     q_sing[3, : B // 2] = -0.0715  # elbow nearly extended: the 6-DOF task loses a direction for half the batch
@@ -400,3 +403,51 @@ def test_gpu_otg_of_task_with_empty_range_waits_like_the_reference():
     # the generator of a robot that waited all along never advanced: still at the state of reinitialize()
     des_q = g.get_jt_desired(2)[0]
     assert (~ever_active).sum() > B // 3 and np.abs(des_q[:, ~ever_active] - q_reg[:, ~ever_active]).max() < 1e-12
+
+
+def test_gpu_certified_range_pass_agrees_with_the_generic_one(monkeypatch):
+    """BASELINE config 4's hierarchy [MFT(3), JT(2), JT(7)] with every generator on, 10 % of the poses near-singular:
+    the range decision ahead of the generators from the SVD-free cascade (+ the generic kernel for the robots it
+    declines) against the generic kernel's for the whole batch (SAI2B_NO_CERT_PATH=1): the generators' states must
+    be bit-equal tick after tick — they only see "active or not" —, the torques agree as two kernels do, and both
+    follow the oracle."""
+    B = 2048 + 19
+    inp = pkg.workloads.make_inputs(4, B=B, seed=77)
+    mk = lambda make: [c for c in make(inp["tasks"])]
+    co, cg, cr = ol.task_configs(inp["tasks"]), pkg.task_configs(inp["tasks"]), pkg.task_configs(inp["tasks"])
+    for cfgs in (co, cg, cr):
+        for c in cfgs:
+            c.use_internal_otg = 1
+    o = ol.Oracle(ol.panda_model(), co, B, threads=8)
+    g = pkg.Controller(pkg.panda_model(), cg, B)
+    monkeypatch.setenv("SAI2B_NO_CERT_PATH", "1")
+    ref = pkg.Controller(pkg.panda_model(), cr, B)
+    monkeypatch.delenv("SAI2B_NO_CERT_PATH")
+    rng = np.random.default_rng(3)
+    for c in (o, g, ref):
+        c.set_state(inp["q"], inp["dq"])
+        c.reinitialize()
+    goals = {1: o.get_jt_desired(1)[0] + rng.normal(0, 0.2, (2, B)), 2: o.get_jt_desired(2)[0] + rng.normal(0, 0.3, (N, B))}
+    for tick in range(12):
+        if tick in (0, 6):
+            for t in (1, 2):
+                goals[t] = goals[t] + rng.normal(0, 0.1, goals[t].shape)
+                for c in (o, g, ref):
+                    c.set_jt_goals(t, goals[t], None, None)
+        tau_o, tau_g, tau_r = o.tick(), g.tick(), ref.tick()
+        _, _, ro = o.get_mft_singularity(0)
+        regular = ro == 3
+        assert _err(tau_g, tau_o)[regular].max() < 10 * TOL and _err(tau_g, tau_o).max() < 1e-6, tick
+        assert _err(tau_g, tau_r)[regular].max() < 10 * TOL
+        for t in (1, 2):
+            for a, b_, c_ in zip(o.get_jt_desired(t), g.get_jt_desired(t), ref.get_jt_desired(t)):
+                assert np.array_equal(b_, c_), (tick, t)
+                assert np.abs(a - b_).max() < 1e-12, (tick, t)
+            for b_, c_ in zip(g.get_otg_status(t), ref.get_otg_status(t)):
+                assert np.array_equal(b_, c_), (tick, t)
+        for c in (o, g, ref):
+            c.sim_step(tau_o, 0.001, 1, with_gravity=False)
+        qo, vo = o.get_state()
+        for c in (g, ref):
+            c.set_state(qo, vo)
+    assert g.fallback_count() < B // 4 and ref.fallback_count() == B  # the two really ran different kernels
