@@ -174,9 +174,73 @@ public:
 	// world transform of a (possibly fixed-attached) link by its URDF name: forward kinematics on the host, same chain
 	// convention as the library (include/sai2b.h: sai2b_robot_model; the base pose is part of the first joint's origin)
 	Eigen::Affine3d transformInWorld(const std::string& link_name) const {
+		double axes[SAI2B_MAX_DOF][3], origins[SAI2B_MAX_DOF][3];
+		int link;
+		return sweep(link_name, link, axes, origins);
+	}
+	// Sai2Model::JWorldFrame(link_name, pos_in_link): 6 x dof, linear rows first (what MotionForceTask.cpp:262 takes), and
+	// its halves / base-frame forms; the velocities of the point are J dq
+	Eigen::MatrixXd JWorldFrame(const std::string& link_name, const Eigen::Vector3d& pos_in_link = Eigen::Vector3d::Zero()) const {
+		double z[SAI2B_MAX_DOF][3], o[SAI2B_MAX_DOF][3];
+		int link;
+		const Eigen::Affine3d T = sweep(link_name, link, z, o);
+		double x[3];
+		for (int a = 0; a < 3; a++) {
+			x[a] = T.translation()(a);
+			for (int b = 0; b < 3; b++) x[a] += T.linear()(a, b) * pos_in_link(b);
+		}
+		const sai2b_robot_model& m = _impl->model();
+		Eigen::MatrixXd J = Eigen::MatrixXd::Zero(6, m.dof);
+		for (int i = 0; i <= link; i++) {
+			const double d[3] = {x[0] - o[i][0], x[1] - o[i][1], x[2] - o[i][2]};
+			const double v[3] = {z[i][1] * d[2] - z[i][2] * d[1], z[i][2] * d[0] - z[i][0] * d[2], z[i][0] * d[1] - z[i][1] * d[0]};
+			const bool prismatic = m.joint_type[i] != 0;
+			for (int a = 0; a < 3; a++) {
+				J(a, i) = prismatic ? z[i][a] : v[a];
+				J(3 + a, i) = prismatic ? 0.0 : z[i][a];
+			}
+		}
+		return J;
+	}
+	Eigen::MatrixXd J(const std::string& link_name, const Eigen::Vector3d& pos_in_link = Eigen::Vector3d::Zero()) const {
+		const Eigen::MatrixXd Jw_ = JWorldFrame(link_name, pos_in_link);
+		const double* Rb = _impl->TRobotBaseRotation();
+		Eigen::MatrixXd Jb = Eigen::MatrixXd::Zero(6, Jw_.cols());
+		for (int h = 0; h < 2; h++)
+			for (int a = 0; a < 3; a++)
+				for (int j = 0; j < (int)Jw_.cols(); j++)
+					for (int k = 0; k < 3; k++) Jb(3 * h + a, j) += Rb[3 * k + a] * Jw_(3 * h + k, j);
+		return Jb;
+	}
+	Eigen::MatrixXd JvWorldFrame(const std::string& l, const Eigen::Vector3d& p = Eigen::Vector3d::Zero()) const { return half(JWorldFrame(l, p), 0); }
+	Eigen::MatrixXd JwWorldFrame(const std::string& l) const { return half(JWorldFrame(l), 1); }
+	Eigen::MatrixXd Jv(const std::string& l, const Eigen::Vector3d& p = Eigen::Vector3d::Zero()) const { return half(J(l, p), 0); }
+	Eigen::MatrixXd Jw(const std::string& l) const { return half(J(l), 1); }
+	Eigen::Vector3d linearVelocityInWorld(const std::string& l, const Eigen::Vector3d& p = Eigen::Vector3d::Zero()) const { return times_dq(JWorldFrame(l, p), 0); }
+	Eigen::Vector3d angularVelocityInWorld(const std::string& l) const { return times_dq(JWorldFrame(l), 1); }
+	Eigen::Vector3d linearVelocity(const std::string& l, const Eigen::Vector3d& p = Eigen::Vector3d::Zero()) const { return times_dq(J(l, p), 0); }
+	Eigen::Vector3d angularVelocity(const std::string& l) const { return times_dq(J(l), 1); }
+	std::shared_ptr<Sai2PrimitivesBatched::BatchedRobotModel>& batched() { return _impl; }
+
+private:
+	static Eigen::MatrixXd half(const Eigen::MatrixXd& J6, int which) {
+		Eigen::MatrixXd H = Eigen::MatrixXd::Zero(3, J6.cols());
+		for (int a = 0; a < 3; a++)
+			for (int j = 0; j < (int)J6.cols(); j++) H(a, j) = J6(3 * which + a, j);
+		return H;
+	}
+	Eigen::Vector3d times_dq(const Eigen::MatrixXd& J6, int which) const {
+		Eigen::Vector3d v = Eigen::Vector3d::Zero();
+		for (int a = 0; a < 3; a++)
+			for (int j = 0; j < (int)J6.cols(); j++) v(a) += J6(3 * which + a, j) * _impl->dq()[j];
+		return v;
+	}
+	// forward kinematics on the host down to the moving link `link_name` hangs on: world transform of the named link,
+	// and for every joint up to there its axis and a point on it, in the world
+	Eigen::Affine3d sweep(const std::string& link_name, int& link, double axes[][3], double origins[][3]) const {
 		const double zero[3] = {0, 0, 0};
 		double fp[3], fr[9];
-		const int link = _impl->resolveLink(link_name, zero, nullptr, fp, fr);
+		link = _impl->resolveLink(link_name, zero, nullptr, fp, fr);
 		const sai2b_robot_model& m = _impl->model();
 		double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
 		for (int i = 0; i <= link; i++) {
@@ -199,7 +263,7 @@ public:
 				if (prismatic) pn[a] += RE[3 * a + 2] * qi;
 			}
 			for (int a = 0; a < 9; a++) R[a] = Rn[a];
-			for (int a = 0; a < 3; a++) p[a] = pn[a];
+			for (int a = 0; a < 3; a++) p[a] = pn[a], axes[i][a] = RE[3 * a + 2], origins[i][a] = pn[a];
 		}
 		Eigen::Affine3d T = Eigen::Affine3d::Identity();
 		for (int a = 0; a < 3; a++) {
@@ -208,9 +272,6 @@ public:
 		}
 		return T;
 	}
-	std::shared_ptr<Sai2PrimitivesBatched::BatchedRobotModel>& batched() { return _impl; }
-
-private:
 	std::shared_ptr<Sai2PrimitivesBatched::BatchedRobotModel> _impl;
 };
 #ifndef SAI2B_EXTERNAL_SAI2_MODEL

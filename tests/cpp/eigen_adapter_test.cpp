@@ -155,6 +155,36 @@ int main(int argc, char** argv) {
 			fwrite(out.data(), sizeof(double), out.size(), stdout);
 			sim.integrate();
 		}
+		// Sai2Model's Jacobians and point velocities (host side of the adapter) against what the device path reports for
+		// the control frame after the last period (MotionForceTask.h:127-133), and against a finite difference of the pose
+		{
+			// (the task's getters look at the state buffers as they are now, one simulation step past the last period)
+			const vector<double> qs = sim.getJointPositions(), dqs = sim.getJointVelocities();
+			VectorXd q_end(dof), dq_end(dof);
+			for (int i = 0; i < dof; i++) q_end(i) = qs[(size_t)i], dq_end(i) = dqs[(size_t)i];
+			robot->setQ(q_end);
+			robot->setDq(dq_end);
+			robot->updateModel();
+			const Vector3d v_host = robot->linearVelocityInWorld(link_name, pos_in_link), w_host = robot->angularVelocityInWorld(link_name);
+			if ((v_host - motion_force_task->getCurrentLinearVelocity()).norm() > 1e-10 ||
+				(w_host - motion_force_task->getCurrentAngularVelocity()).norm() > 1e-10)
+				return 9;
+			const MatrixXd Jh = robot->JWorldFrame(link_name, pos_in_link);
+			if (Jh.rows() != 6 || Jh.cols() != dof || robot->Jv(link_name, pos_in_link).rows() != 3 || robot->JwWorldFrame(link_name).cols() != dof) return 9;
+			const VectorXd q_now = robot->q();
+			const double h = 1e-6;
+			for (int j = 0; j < dof; j++) {
+				VectorXd qp = q_now, qm = q_now;
+				qp(j) += h, qm(j) -= h;
+				robot->setQ(qp);
+				const Vector3d xp = robot->positionInWorld(link_name, pos_in_link);
+				robot->setQ(qm);
+				const Vector3d xm = robot->positionInWorld(link_name, pos_in_link);
+				for (int a = 0; a < 3; a++)
+					if (fabs((xp(a) - xm(a)) / (2 * h) - Jh(a, j)) > 1e-8) return 9;
+			}
+			robot->setQ(q_now);
+		}
 		// Sai2PrimitivesCommonDefinitions.h:25-27
 		const VectorXd kp = Sai2Primitives::extractKpFromGainVector(joint_task->getGains());
 		if (kp.size() != 1 || kp(0) != 50.0 || Sai2Primitives::extractKvFromGainVector(joint_task->getGains())(0) != 14.0 ||
