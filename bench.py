@@ -167,19 +167,43 @@ def main():
         ctrl.tick(want_output=False)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        ctrl.tick(want_output=False)
-    ev1.record(stream)
-    barrier()  # ctx stream drained + device synchronize + all ranks arrived
-    elapsed = time.perf_counter() - t0
-    step_ms_events = ev0.elapsed_time(ev1) / args.steps  # HIP events on the ctx stream, whole step
-    # per-kernel durations, HIP events around each launch on the ctx stream (outside the timed region)
-    kernel_ms, fallback_ms = ctrl.profile_tick(min(args.steps, 100))
-    # the slowest rank defines the job: MAX over ranks (the only communication of the whole run)
-    elapsed, step_ms_events, kernel_ms, fallback_ms = pkg.sharding.max_over_ranks(
-        [elapsed, step_ms_events, kernel_ms, fallback_ms], device=red_device)
+
+    def window():
+        """EXACTLY args.steps steps between two barriers (ctx stream drained + device synchronize + all ranks arrived)"""
+        barrier()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(args.steps):
+            ctrl.tick(want_output=False)
+        ev1.record(stream)
+        barrier()
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1) / args.steps  # wall; HIP events on the ctx stream
+
+    # A window of K steps is K x ~30 us: with the default K that is a few ms, with --steps 20 well under one, and a
+    # single such window measures the clock ramp and one host wake-up more than the kernel. When the window is shorter
+    # than 50 ms it is repeated (>= 9 windows, >= 50 ms of work in all) and the MEDIAN window is reported; every window
+    # is timed as the contract says (K steps, barrier + synchronize on both sides, MAX over ranks).
+    first = window()
+    (w0,) = pkg.sharding.max_over_ranks([first[0]], device=red_device)
+    n_windows = 1 if w0 >= 0.05 else int(min(400, max(9, np.ceil(0.05 / max(w0, 1e-6)))))
+    walls, evs = [], []
+    for _ in range(n_windows):
+        w, e = window()
+        walls.append(w)
+        evs.append(e)
+    # the slowest rank defines each window: MAX over ranks (the only communication of the whole run), then the median
+    red = pkg.sharding.max_over_ranks(walls + evs, device=red_device)
+    walls, evs = np.asarray(red[:n_windows]), np.asarray(red[n_windows:])
+    mid = int(np.argsort(walls)[n_windows // 2])
+    elapsed, step_ms_events = float(walls[mid]), float(np.median(evs))
+    # per-kernel durations (outside the timed region): ONE event pair around back-to-back launches of the dominant
+    # kernel alone, then around the tick's launch sequence (sai2b_profile_tick): the two parts add up to a step
+    for attempt in range(3):
+        kernel_ms, fallback_ms = ctrl.profile_tick(max(50, min(args.steps, 200)))
+        kernel_ms, fallback_ms = pkg.sharding.max_over_ranks([kernel_ms, fallback_ms], device=red_device)
+        consistent = kernel_ms + fallback_ms <= step_ms_events * 1.02 and kernel_ms <= step_ms_events
+        if consistent:
+            break
     pkg.sharding.barrier()
 
     if rank == 0:
@@ -194,6 +218,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "timed_windows": {"count": n_windows, "reported": "median", "ms_per_step_min": float(walls.min()) / args.steps * 1e3,
+                              "ms_per_step_max": float(walls.max()) / args.steps * 1e3},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -222,9 +248,11 @@ def main():
                 "kernel_ms": kernel_ms,
                 "fallback_kernel_ms": fallback_ms,
                 "step_ms_hip_events": step_ms_events,
+                "parts_sum_to_step": bool(consistent),
                 "fp64_vector_frac": (FLOP_PER_TICK * B / (kernel_ms * 1e-3)) / (FP64_VECTOR_PEAK_TFLOPS * 1e12),
-                "note": "achieved = algorithmic bytes/tick (SURVEY.md §8(d): 360/528/576 B for C2/C3/C4) x robots per launch / HIP-event duration of the "
-                        "dominant kernel; the path is FP64-VALU/latency bound, so the FP64 fraction (11.4 kflop/tick "
+                "note": "achieved = algorithmic bytes/tick (SURVEY.md §8(d): 360/528/576 B for C2/C3/C4) x robots per launch / average launch duration of the "
+                        "dominant kernel (one HIP event pair around back-to-back launches of it on the ctx stream); fallback_kernel_ms = what the "
+                        "work-list pass behind it adds to a step; the path is FP64-VALU/latency bound, so the FP64 fraction (11.4 kflop/tick "
                         "formula-level figure) is reported beside the HBM fraction. traffic = 2*FETCH_SIZE + WRITE_SIZE "
                         "of the committed rocprofv3 --pmc passes of this command (profiles/), per launch. Measured FP64 FMA "
                         "issue ceilings (profiles/r01_fp64_fma_microbench.txt): 60 TF chip peak, 30 TF with one wavefront "

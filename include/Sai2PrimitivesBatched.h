@@ -735,6 +735,14 @@ public:
 		_cfg.enforce_handling_strategy = on;
 		syncConfig();
 	}
+	// Not in the reference: the orientation of the singular vector classifySingularity perturbs along
+	// (SingularityHandler.cpp:253-265 takes V_s as Eigen::JacobiSVD left it; enum sai2b_singular_vector_sign)
+	void setSingularVectorSign(const int convention) {
+		if (convention < SAI2B_SV_SIGN_V_MAX_POSITIVE || convention > SAI2B_SV_SIGN_BOTH)
+			throw std::invalid_argument("singular vector sign convention must be one of enum sai2b_singular_vector_sign");
+		_cfg.singular_vector_sign = convention;
+		syncConfig();
+	}
 	// singular values of the projected Jacobian of the last tick, [6][B] (examples/18 logs these)
 	inline Batch getSigmaValues() const;
 

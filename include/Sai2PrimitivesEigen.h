@@ -540,6 +540,8 @@ public:
 	void resetIntegratorsAngular() { _t->resetIntegratorsAngular(); }
 	// singularity handling (MotionForceTask.h:669-753)
 	void handleAllSingularitiesAsType1(const bool flag) { _t->handleAllSingularitiesAsType1(flag); }
+	// not in the reference: see Sai2PrimitivesBatched.h (the sign Eigen's JacobiSVD leaves on V_s is not reproduced)
+	void setSingularVectorSign(const int convention) { _t->setSingularVectorSign(convention); }
 	void setType1Posture(const VectorXd& q_des) { _t->setType1Posture(D_::batch_of(q_des)); }
 	void enableSingularityHandling() { _t->enableSingularityHandling(true); }
 	void disableSingularityHandling() { _t->disableSingularityHandling(); }

@@ -44,6 +44,21 @@ enum sai2b_decoupling {
 	SAI2B_IMPEDANCE = 2
 };
 
+/* Orientation of the singular vectors the singularity classification perturbs along. The reference classifies a
+ * singular direction by forward kinematics at q + 5 * V_s[:, i] (SingularityHandler.cpp:253-265) where V_s comes out
+ * of Eigen::JacobiSVD (:78-81), and a singular vector is only defined up to its sign: FK(q + 5 v) and FK(q - 5 v) are
+ * different poses, so "type 1" vs "type 2" — two different control strategies (:328-351) — can depend on a sign Eigen
+ * does not specify and this library cannot reproduce without Eigen. The convention is therefore DEFINED here and
+ * selectable per MotionForceTask; how many robots it matters for is measured in tests/test_gpu_svd_sign.py and
+ * recorded in DESIGN.md §2 / INTEGRATION.md §6. Nothing else on the path depends on the sign (every other use of
+ * U_s, V_s is a product v v^T or an absolute value). */
+enum sai2b_singular_vector_sign {
+	SAI2B_SV_SIGN_V_MAX_POSITIVE = 0, /* default: the largest-magnitude component of V_s[:, i] is positive */
+	SAI2B_SV_SIGN_V_MAX_NEGATIVE = 1, /* the opposite orientation */
+	SAI2B_SV_SIGN_EITHER = 2,		  /* sign-free: type 1 if the perturbation along +v OR -v moves the task */
+	SAI2B_SV_SIGN_BOTH = 3			  /* sign-free: type 1 only if both do */
+};
+
 /* error codes */
 enum sai2b_status {
 	SAI2B_OK = 0,
@@ -127,6 +142,7 @@ typedef struct sai2b_task_config {
 	int sh_buffer_size;
 	double kp_type_1, kv_type_1, kv_type_2;
 	int enforce_type_1_strategy, enforce_handling_strategy;
+	int singular_vector_sign; /* enum sai2b_singular_vector_sign: classifySingularity's perturbation direction */
 
 	/* ---- internal online trajectory generation (JointTask.h:38-42,294-324;
 	 * MotionForceTask.h:67-74,387-427): on by default, acceleration-limited. The desired state fed
@@ -432,9 +448,12 @@ int sai2b_get_otg_status(sai2b_ctx* ctx, int task, double* goal_reached, double*
 /* Sai2Model::M(): [49][B]; J of MFT `task` (JWorldFrame): [42][B]; position [3][B], rotation [9][B] */
 int sai2b_get_model(sai2b_ctx* ctx, int task, double* M, double* J, double* pos, double* rot);
 
-/* Bench bookkeeping: run `steps` fused ticks with HIP events around each kernel launch of the tick (on
- * the ctx stream) and return the average duration per launch in ms: the first kernel of the tick and,
- * when the hierarchy takes the SVD-free path, the generic kernel over its work list behind it (else 0). */
+/* Bench bookkeeping (on the ctx stream, ONE HIP event pair around `steps` back-to-back launches, so no event sits
+ * between two kernels): first the first kernel of the tick alone — its average duration per launch in ms —, then the
+ * tick's whole launch sequence; second_kernel_ms = what the generic kernel over the work list behind an SVD-free
+ * kernel adds to a step (0 when the hierarchy has no such pass). The two add up to the step. The ticks run for real
+ * (integrators, generators and singularity histories advance; in the first phase the robots the SVD-free kernel
+ * declines are not served): a profiling call, not part of a control loop. */
 int sai2b_profile_tick(sai2b_ctx* ctx, int steps, double* first_kernel_ms, double* second_kernel_ms);
 
 /* How many robots of the last tick the SVD-free kernel handed to the generic (Jacobi-SVD) kernel: those

@@ -18,7 +18,7 @@
 
 #include <math.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define SAI2B_DET_FN __host__ __device__ static inline
 #else
 #define SAI2B_DET_FN static inline

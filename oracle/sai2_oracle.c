@@ -155,7 +155,8 @@ static void hestenes(int rows, int cols, double* X, double* W) {
 /* Thin SVD A (m x n) = U diag(s) V^T with p = min(m,n): U m x p, s p (descending), V n x p.
  * Stands in for Eigen::JacobiSVD(ComputeThinU|ComputeThinV) (SingularityHandler.cpp:78-81).
  * Singular vectors of distinct non-zero singular values are unique up to sign; every use on the
- * path is sign-invariant. Columns belonging to s == 0 on the normalised side are set to zero. */
+ * path but ONE is sign-invariant: classifySingularity perturbs q along V_s[:, i] (sh_classify below,
+ * enum sai2b_singular_vector_sign). Columns belonging to s == 0 on the normalised side are set to zero. */
 void oracle_svd(int m, int n, const double* A, double* U, double* s, double* V) {
 	double X[MAXD * MAXD], W[MAXD * MAXD];
 	int p = m < n ? m : n;
@@ -1009,16 +1010,32 @@ static void sh_classify(const oracle_ctx* c, const sai2b_task_config* t, const r
 	frame_pose(t, r->Rl, r->pl, x0, R0);
 	int any1 = 0;
 	for (int i = 0; i < s->sc; i++) {
-		double qp[N7], Rl[N7][9], pl[N7][3], x1[3], R1[9], d[6];
-		for (int j = 0; j < N7; j++) qp[j] = r->q[j] + t->perturb_step_size * s->V_s[j * s->sc + i];
-		fk(c, qp, Rl, pl);
-		frame_pose(t, Rl, pl, x1, R1);
-		for (int k = 0; k < 3; k++) d[k] = x1[k] - x0[k];
-		orientation_error(R1, R0, d + 3);
-		double m = 0;
-		for (int k = 0; k < 6; k++) m += d[k] * s->U_s[k * s->sc + i];
-		s->types[i] = fabs(m) > t->type_1_tol ? 1 : 2;
-		if (s->types[i] == 1) any1 = 1;
+		/* The perturbation direction is V_s[:, i] as Eigen's JacobiSVD leaves it in the reference (:78-81, :254); its
+		 * sign is not specified there, so it is a setting here (enum sai2b_singular_vector_sign; oracle_svd orients
+		 * every right singular vector "largest-magnitude component positive"): that orientation, the opposite one, or
+		 * the two sign-free rules "either" / "both". */
+		int moved[2] = {0, 0};
+		for (int pass = 0; pass < 2; pass++) {
+			const double step = pass ? -t->perturb_step_size : t->perturb_step_size;
+			double qp[N7], Rl[N7][9], pl[N7][3], x1[3], R1[9], d[6];
+			for (int j = 0; j < N7; j++) qp[j] = r->q[j] + step * s->V_s[j * s->sc + i];
+			fk(c, qp, Rl, pl);
+			frame_pose(t, Rl, pl, x1, R1);
+			for (int k = 0; k < 3; k++) d[k] = x1[k] - x0[k];
+			orientation_error(R1, R0, d + 3);
+			double m = 0;
+			for (int k = 0; k < 6; k++) m += d[k] * s->U_s[k * s->sc + i];
+			moved[pass] = fabs(m) > t->type_1_tol;
+		}
+		int type1;
+		switch (t->singular_vector_sign) {
+			case SAI2B_SV_SIGN_V_MAX_NEGATIVE: type1 = moved[1]; break;
+			case SAI2B_SV_SIGN_EITHER: type1 = moved[0] || moved[1]; break;
+			case SAI2B_SV_SIGN_BOTH: type1 = moved[0] && moved[1]; break;
+			default: type1 = moved[0];
+		}
+		s->types[i] = type1 ? 1 : 2;
+		if (type1) any1 = 1;
 	}
 	int cap = t->sh_buffer_size;
 	if (cap > SAI2B_SH_HISTORY) cap = SAI2B_SH_HISTORY;

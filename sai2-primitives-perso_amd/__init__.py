@@ -12,6 +12,10 @@ from ._abi import (  # noqa: F401
     JOINT_TASK,
     MOTION_FORCE_TASK,
     RobotModel,
+    SV_SIGN_BOTH,
+    SV_SIGN_EITHER,
+    SV_SIGN_V_MAX_NEGATIVE,
+    SV_SIGN_V_MAX_POSITIVE,
     TaskConfig,
 )
 from .controller import (  # noqa: F401,E402

@@ -16,6 +16,9 @@ SH_HISTORY = 200
 UNDEFINED, JOINT_TASK, MOTION_FORCE_TASK = 0, 1, 2
 # enum sai2b_decoupling (reference src/helper_modules/Sai2PrimitivesCommonDefinitions.h:9-15)
 FULL_DYNAMIC_DECOUPLING, BOUNDED_INERTIA_ESTIMATES, IMPEDANCE = 0, 1, 2
+# enum sai2b_singular_vector_sign (not in the reference: the orientation of the singular vector classifySingularity
+# perturbs along, SingularityHandler.cpp:253-265)
+SV_SIGN_V_MAX_POSITIVE, SV_SIGN_V_MAX_NEGATIVE, SV_SIGN_EITHER, SV_SIGN_BOTH = 0, 1, 2, 3
 # enum sai2b_status
 OK, INVALID_ARGUMENT, RUNTIME_ERROR, UNSUPPORTED = 0, 1, 2, 3
 # enum sai2b_buffer
@@ -109,6 +112,7 @@ class TaskConfig(C.Structure):
         ("kv_type_2", _d),
         ("enforce_type_1_strategy", _i),
         ("enforce_handling_strategy", _i),
+        ("singular_vector_sign", _i),
         # internal OTG
         ("use_internal_otg", _i),
         ("internal_otg_jerk_limited", _i),

@@ -305,6 +305,13 @@ class Controller:
         self._rc(self.lib.sai2b_get_mft_singularity_state(self.h, task, C.c_void_p(n.ctypes.data), None, None))
         return n
 
+    def get_mft_singularity_state(self, task):
+        """per robot: singular directions of the last model update, type-1 and type-2 counts of the handler's history
+        (SingularityHandler.h:211-215); no introspection needed"""
+        n, c1, c2 = (np.empty(self.B, dtype=np.int32) for _ in range(3))
+        self._rc(self.lib.sai2b_get_mft_singularity_state(self.h, task, *[C.c_void_p(x.ctypes.data) for x in (n, c1, c2)]))
+        return n, c1, c2
+
     def synchronize(self):
         self._rc(self.lib.sai2b_synchronize(self.h))
 
@@ -1059,6 +1066,14 @@ class MotionForceTask(_TaskBase):
 
     def disableSingularityHandling(self):
         self._cfg.enforce_handling_strategy = 0
+        self._sync_cfg()
+
+    def setSingularVectorSign(self, convention):
+        """Not in the reference: which way classifySingularity perturbs along a singular vector
+        (SingularityHandler.cpp:253-265 uses V_s as Eigen's JacobiSVD left it, a sign Eigen does not specify).
+        0 = largest-magnitude component of V_s[:, i] positive (default), 1 = the opposite, 2 = type 1 if either
+        direction moves the task, 3 = only if both do (enum sai2b_singular_vector_sign)."""
+        self._cfg.singular_vector_sign = int(convention)
         self._sync_cfg()
 
     def setFeedforwardForceGain(self, kff):

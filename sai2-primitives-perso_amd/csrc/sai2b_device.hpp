@@ -941,17 +941,30 @@ DI void mft_task(const DevParams& P, const DevTask& t, const RobotCtx& rc, int B
 				UNROLL for (int i = 0; i < N; i++) vs0[i] = v[i];
 			}
 			UNROLL for (int i = 0; i < N; i++) UNROLL for (int k = 0; k < N; k++) PV[i * N + k] = fma(v[i], v[k], PV[i * N + k]);
-			// classification by FK perturbation (:253-273)
-			real qp[N], x1[3], R1[9], d[6];
-			UNROLL for (int i = 0; i < N; i++) qp[i] = fma(t.perturb, v[i], rc.q[i]);
-			Frames F1;
-			fk(P.model, qp, F1);
-			frame_pose(t, F1, x1, R1);
-			UNROLL for (int k = 0; k < 3; k++) d[k] = x1[k] - x[k];
-			orientation_error(R1, R, d + 3);
-			real m = 0;
-			UNROLL for (int k = 0; k < 6; k++) m = fma(d[k], u[k], m);
-			any1 = any1 || (fabs(m) > t.type_1_tol);
+			// classification by FK perturbation (:253-273) along +v, -v or both (enum sai2b_singular_vector_sign: the
+			// reference perturbs along V_s[:, i] as Eigen left it, a sign it does not specify)
+			bool moved[2] = {false, false};
+			const int pass0 = t.sv_sign == SAI2B_SV_SIGN_V_MAX_NEGATIVE ? 1 : 0;
+			const int pass1 = t.sv_sign == SAI2B_SV_SIGN_V_MAX_POSITIVE ? 0 : 1;
+#pragma unroll 1
+			for (int pass = pass0; pass <= pass1; pass++) {
+				const real step = pass ? -t.perturb : t.perturb;
+				real qp[N], x1[3], R1[9], d[6];
+				UNROLL for (int i = 0; i < N; i++) qp[i] = fma(step, v[i], rc.q[i]);
+				Frames F1;
+				fk(P.model, qp, F1);
+				frame_pose(t, F1, x1, R1);
+				UNROLL for (int k = 0; k < 3; k++) d[k] = x1[k] - x[k];
+				orientation_error(R1, R, d + 3);
+				real m = 0;
+				UNROLL for (int k = 0; k < 6; k++) m = fma(d[k], u[k], m);
+				if (pass)
+					moved[1] = fabs(m) > t.type_1_tol;
+				else
+					moved[0] = fabs(m) > t.type_1_tol;
+			}
+			const bool type1 = t.sv_sign == SAI2B_SV_SIGN_BOTH ? (moved[0] && moved[1]) : (moved[0] || moved[1]);
+			any1 = any1 || type1;
 		}
 		if (commit_sh) {  // history ring (:276-293)
 			int count = ldi(IS, IS_COUNT, B, b), size = ldi(IS, IS_SIZE, B, b);

@@ -568,15 +568,25 @@ SAI2B_TASK_FN void mft_task_g(const DevParams& P, const DevTask& t, const Rob& r
 				vs0 = v;
 			}
 			lanefma<G, N>(pv, v, v);  // PV += v v^T
-			// classification by FK perturbation (:253-273)
-			real R1f[9], p1f[3], x1[3], R1[9], dd[6];
-			fk_scan<G>(P.model, r, fma(t.perturb, v, rb.q), R1f, p1f);
-			frame_pose_g<G>(t, R1f, p1f, x1, R1);
-			UNROLL for (int k = 0; k < 3; k++) dd[k] = x1[k] - x[k];
-			orientation_error(R1, R, dd + 3);
-			real m = 0;
-			UNROLL for (int k = 0; k < 6; k++) m = fma(dd[k], u[k], m);
-			any1 = any1 || (fabs(m) > t.type_1_tol);
+			// classification by FK perturbation (:253-273) along +v, -v or both (enum sai2b_singular_vector_sign; the
+			// setting is batch-uniform, so the passes are uniform over the wavefront)
+			bool moved0 = false, moved1 = false;
+			const int pass0 = t.sv_sign == SAI2B_SV_SIGN_V_MAX_NEGATIVE ? 1 : 0;
+			const int pass1 = t.sv_sign == SAI2B_SV_SIGN_V_MAX_POSITIVE ? 0 : 1;
+#pragma unroll 1
+			for (int pass = pass0; pass <= pass1; pass++) {
+				real R1f[9], p1f[3], x1[3], R1[9], dd[6];
+				fk_scan<G>(P.model, r, fma(pass ? -t.perturb : t.perturb, v, rb.q), R1f, p1f);
+				frame_pose_g<G>(t, R1f, p1f, x1, R1);
+				UNROLL for (int k = 0; k < 3; k++) dd[k] = x1[k] - x[k];
+				orientation_error(R1, R, dd + 3);
+				real m = 0;
+				UNROLL for (int k = 0; k < 6; k++) m = fma(dd[k], u[k], m);
+				const bool mv = fabs(m) > t.type_1_tol;
+				moved0 = pass ? moved0 : mv;
+				moved1 = pass ? mv : moved1;
+			}
+			any1 = any1 || (t.sv_sign == SAI2B_SV_SIGN_BOTH ? (moved0 && moved1) : (moved0 || moved1));
 		}
 		if (commit_sh) {  // history ring (:276-293); every lane of the group computes and stores the same values
 			int count = ldi(IS, IS_COUNT, B, b), size = ldi(IS, IS_SIZE, B, b);

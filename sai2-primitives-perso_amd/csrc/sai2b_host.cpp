@@ -406,6 +406,8 @@ extern "C" int sai2b_validate_tasks(const sai2b_task_config* tasks, int n_tasks,
 					err = "MotionForceTask: partial_projection must be an orthogonal projector of rank pos_range + ori_range >= 1";
 			}
 		}
+		if (err.empty() && (t.singular_vector_sign < SAI2B_SV_SIGN_V_MAX_POSITIVE || t.singular_vector_sign > SAI2B_SV_SIGN_BOTH))
+			err = "singular_vector_sign must be one of enum sai2b_singular_vector_sign";
 		if (err.empty() && (t.dynamic_decoupling_type < SAI2B_FULL_DYNAMIC_DECOUPLING || t.dynamic_decoupling_type > SAI2B_IMPEDANCE))
 			err = "dynamic_decoupling_type must be FULL_DYNAMIC_DECOUPLING, BOUNDED_INERTIA_ESTIMATES or IMPEDANCE";
 		if (err.empty() && t.use_internal_otg) {
@@ -559,6 +561,7 @@ static void fill_dev_task(const sai2b_task_config& c, DevTask& d) {
 	d.sh_cap = c.sh_buffer_size;
 	d.kp1 = c.kp_type_1, d.kv1 = c.kv_type_1, d.kv2 = c.kv_type_2;
 	d.enforce_t1 = c.enforce_type_1_strategy, d.enforce = c.enforce_handling_strategy;
+	d.sv_sign = c.singular_vector_sign;
 	// internal OTG: one generator DoF per task dof (JT) or 3 linear + 3 angular (MFT)
 	d.otg_on = c.use_internal_otg ? 1 : 0;
 	d.otg_n = c.type == SAI2B_JOINT_TASK ? c.task_dof : 6;
@@ -1106,6 +1109,9 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 
 static int fetch_tau(sai2b_ctx* ctx, double* tau, int on_device) {
 	if (!tau) return SAI2B_OK;
+	// a device result is written on the ctx stream: what the caller's stream still does with that buffer comes first
+	if (on_device)
+		if (int rc = caller_before_read(ctx)) return rc;
 	HIP_TRY(ctx, hipMemcpyAsync(tau, ctx->tau, (size_t)N * ctx->B * sizeof(double),
 								on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // a returned tau is complete, host or device
@@ -1236,7 +1242,9 @@ extern "C" int sai2b_task_compute_torques(sai2b_ctx* ctx, int task, const double
 	ctx->ticks += ctx->B;
 	io.model_fresh = false;
 	ctx->q_is_pose = true;	// computeTorques caches the task's current pose
-	if (!tau) return SAI2B_OK;
+	// a device tau_prec was read in place: the caller may overwrite it once this call has returned
+	if (!tau) return (tau_prec && on_device) ? caller_after_read(ctx) : SAI2B_OK;
+	if (on_device && (rc = caller_before_read(ctx))) return rc;
 	HIP_TRY(ctx, hipMemcpyAsync(tau, io.tau, (size_t)N * ctx->B * sizeof(double), on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
 								ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1293,7 +1301,13 @@ extern "C" int sai2b_synchronize(sai2b_ctx* ctx) {
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return SAI2B_OK;
 }
-extern "C" void* sai2b_stream(sai2b_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+// (a deferred model update is enqueued before the stream is handed out; a caller that keeps the handle, or a
+// buffer pointer, across later sai2b_update_task_models() calls flushes with sai2b_synchronize() — INTEGRATION.md §4)
+extern "C" void* sai2b_stream(sai2b_ctx* ctx) {
+	if (!ctx) return nullptr;
+	flush_update(ctx);
+	return (void*)ctx->stream;
+}
 extern "C" int sai2b_set_caller_stream(sai2b_ctx* ctx, void* stream) {
 	if (!ctx) return set_error(nullptr, SAI2B_INVALID_ARGUMENT, "null ctx");
 	ctx->caller_stream = (hipStream_t)stream;
@@ -1454,7 +1468,9 @@ extern "C" int sai2b_get_bias(sai2b_ctx* ctx, int with_gravity, double* bias) {
 }
 
 static int run_status(sai2b_ctx* ctx, int task) {
-	int rc = upload_params(ctx);
+	int rc = flush_update(ctx);	 // a deferred model update (and its launch errors) happens before anything is observed
+	if (rc) return rc;
+	rc = upload_params(ctx);
 	if (rc) return rc;
 	if (!ctx->status_buf && (rc = dev_alloc(ctx, &ctx->status_buf, 68 * (size_t)ctx->B))) return rc;
 	if (sai2b_launch_mft_status(ctx->d_params, ctx->B, task, ctx->status_buf, ctx->stream))
@@ -1576,9 +1592,10 @@ extern "C" int sai2b_get_mft_desired(sai2b_ctx* ctx, int task, double* pos, doub
 extern "C" int sai2b_get_otg_status(sai2b_ctx* ctx, int task, double* goal_reached, double* result) {
 	if (!ctx || task < 0 || task >= ctx->T) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_get_otg_status: bad arguments");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	const double* S = ctx->h_params.task[task].otg_state;
-	int rc = fetch_rows(ctx, S, sai2b::OTG_GOAL_REACHED, 1, goal_reached);
+	int rc = flush_update(ctx);
 	if (rc) return rc;
+	const double* S = ctx->h_params.task[task].otg_state;
+	if ((rc = fetch_rows(ctx, S, sai2b::OTG_GOAL_REACHED, 1, goal_reached))) return rc;
 	return fetch_rows(ctx, S, sai2b::OTG_RESULT, 1, result);
 }
 
@@ -1608,32 +1625,36 @@ extern "C" int sai2b_profile_tick(sai2b_ctx* ctx, int steps, double* first_ms, d
 	if (rc) return rc;
 	const int fast = fast_kind(ctx);
 	const bool two = fast != 0 && !ctx->introspection;
-	std::vector<hipEvent_t> ev(3 * (size_t)steps);
-	for (auto& e : ev) HIP_TRY(ctx, hipEventCreate(&e));
-	for (int s = 0; s < steps; s++) {
-		HIP_TRY(ctx, hipEventRecord(ev[3 * s], ctx->stream));
-		if (two) ctx->fb_parity ^= 1;
-		if (sai2b_launch_tick_part(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, ctx->baked_model ? 1 : 0, 0, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, !two), ctx->stream))
-			return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
-		HIP_TRY(ctx, hipEventRecord(ev[3 * s + 1], ctx->stream));
-		if (two && sai2b_launch_tick_part(ctx->d_params, ctx->B, 0, fast, ctx->baked_model ? 1 : 0, 1, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, false), ctx->stream))
-			return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
-		HIP_TRY(ctx, hipEventRecord(ev[3 * s + 2], ctx->stream));
+	// ONE event pair around `steps` back-to-back launches (an event pair per launch costs ~4 us of its own, which made
+	// the two parts add up to more than the step): first the first kernel alone, then the sequence of a tick. The
+	// second figure is what the work-list pass adds to a step, so the two sum to the step by construction.
+	hipEvent_t e0, e1;
+	HIP_TRY(ctx, hipEventCreate(&e0));
+	HIP_TRY(ctx, hipEventCreate(&e1));
+	double part_ms[2] = {0, 0};
+	for (int phase = 0; phase < (two ? 2 : 1); phase++) {
+		for (int rep = 0; rep < 2; rep++) {	 // (the first repetition warms the sequence up)
+			HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+			for (int s = 0; s < steps; s++) {
+				if (two) ctx->fb_parity ^= 1;
+				if (sai2b_launch_tick_part(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, ctx->baked_model ? 1 : 0, 0, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, !two), ctx->stream))
+					return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
+				if (phase == 1 && sai2b_launch_tick_part(ctx->d_params, ctx->B, 0, fast, ctx->baked_model ? 1 : 0, 1, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, false), ctx->stream))
+					return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
+			}
+			HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+			float ms = 0;
+			HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+			part_ms[phase] = ms / steps;
+		}
 	}
-	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-	double a = 0, b = 0;
-	for (int s = 0; s < steps; s++) {
-		float ms = 0;
-		HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[3 * s], ev[3 * s + 1]));
-		a += ms;
-		HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[3 * s + 1], ev[3 * s + 2]));
-		b += ms;
-	}
-	for (auto& e : ev) (void)hipEventDestroy(e);
-	ctx->launches += (two ? 2 : 1) * (long long)steps;
-	ctx->ticks += (long long)steps * ctx->B;
-	if (first_ms) *first_ms = a / steps;
-	if (second_ms) *second_ms = two ? b / steps : 0.0;
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	ctx->launches += (two ? 6 : 2) * (long long)steps;
+	ctx->ticks += (two ? 4 : 2) * (long long)steps * ctx->B;
+	if (first_ms) *first_ms = part_ms[0];
+	if (second_ms) *second_ms = two ? std::max(0.0, part_ms[1] - part_ms[0]) : 0.0;
 	return SAI2B_OK;
 }
 

@@ -66,6 +66,7 @@ struct DevTask {
 	int sh_cap;
 	double kp1, kv1, kv2;
 	int enforce_t1, enforce;
+	int sv_sign;  // enum sai2b_singular_vector_sign (include/sai2b.h): classifySingularity's perturbation direction
 	// internal OTG (JointTask.h:38-42, MotionForceTask.h:67-74); limits per OTG DoF (JT: task dof;
 	// MFT: 3 linear then 3 angular)
 	int otg_on, otg_n;

@@ -152,7 +152,9 @@ bool numbers(const std::string& text, int n, double* out) {
 		if (k >= n) return false;
 		char* end = nullptr;
 		out[k] = std::strtod(tok.c_str(), &end);
-		if (end == tok.c_str()) return false;
+		// (strtod also reads "nan", "inf" and overflows to HUGE_VAL: a model with such an entry would put NaNs into every
+		// robot's torques — found by tests/test_sanitized_host.py)
+		if (end == tok.c_str() || !std::isfinite(out[k])) return false;
 		k++;
 	}
 	return k == n;
@@ -268,6 +270,10 @@ extern "C" int sai2b_model_from_urdf(const char* urdf, int is_file, sai2b_robot_
 			Link l;
 			if (!e.attr.count("name")) return fail("URDF: <link> without a name");
 			l.name = e.attr.at("name");
+			// (sai2b_urdf_links holds 63 characters + NUL per name: a longer one would be cut and could then collide)
+			if (l.name.empty() || l.name.size() >= sizeof(sai2b_urdf_links{}.name[0])) return fail("URDF: link name empty or longer than 63 characters");
+			for (const Link& other : lk)
+				if (other.name == l.name) return fail("URDF: two links named " + l.name);
 			const int in = px.child(c, "inertial");
 			if (in >= 0) {
 				l.in.present = true;
@@ -307,9 +313,8 @@ extern "C" int sai2b_model_from_urdf(const char* urdf, int is_file, sai2b_robot_
 			if (lim >= 0) {
 				const auto& a = px.nodes[lim].attr;
 				j.has_limit = true;
-				if (a.count("lower")) numbers(a.at("lower"), 1, &j.lower);
-				if (a.count("upper")) numbers(a.at("upper"), 1, &j.upper);
-				if (a.count("effort")) numbers(a.at("effort"), 1, &j.effort);
+				for (const auto& kv : {std::make_pair("lower", &j.lower), std::make_pair("upper", &j.upper), std::make_pair("effort", &j.effort)})
+					if (a.count(kv.first) && !numbers(a.at(kv.first), 1, kv.second)) return fail("URDF: bad limit of joint " + j.name);
 			}
 			jt.push_back(j);
 		}

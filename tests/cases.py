@@ -71,6 +71,8 @@ def apply_opts(cfg, opts):
             cfg.enforce_type_1_strategy = int(v)
         elif k == "enforce_handling":
             cfg.enforce_handling_strategy = int(v)
+        elif k == "sv_sign":
+            cfg.singular_vector_sign = int(v)
         else:
             raise KeyError(k)
     return cfg

@@ -372,6 +372,7 @@ class MotionForceTaskNP:
         self.kp1, self.kv1, self.kv2 = 50.0, 14.0, 5.0
         self.enforce_t1 = opt.get("enforce_type_1", False)
         self.enforce = opt.get("enforce_handling", True)
+        self.sv_sign = opt.get("sv_sign", 0)  # enum sai2b_singular_vector_sign (include/sai2b.h)
         self.dt = 0.001
         self.N_prec = np.eye(N)
         self.types, self.hist, self.c1, self.c2 = [], [], 0, 0
@@ -482,10 +483,14 @@ class MotionForceTaskNP:
         x0, R0 = self.pose()
         self.types = []
         for i in range(self.sc):
-            Rl, pl = fk(rb.q + self.perturb * self.V_s[:, i])
-            x1, R1 = self.pose(Rl, pl)
-            d = np.concatenate([x1 - x0, orientation_error(R1, R0)])
-            self.types.append(1 if abs(d @ self.U_s[:, i]) > self.type1_tol else 2)
+            moved = []
+            for step in (self.perturb, -self.perturb):  # the sign of V_s[:, i] is a setting (include/sai2b.h)
+                Rl, pl = fk(rb.q + step * self.V_s[:, i])
+                x1, R1 = self.pose(Rl, pl)
+                d = np.concatenate([x1 - x0, orientation_error(R1, R0)])
+                moved.append(abs(d @ self.U_s[:, i]) > self.type1_tol)
+            t1 = {0: moved[0], 1: moved[1], 2: moved[0] or moved[1], 3: moved[0] and moved[1]}[self.sv_sign]
+            self.types.append(1 if t1 else 2)
         if 1 in self.types:
             self.hist.append(1)
             self.c1 += 1

@@ -343,9 +343,8 @@ def test_random_runtime_events_closed_loop(seed):
         den = np.maximum(np.abs(tau_o).max(axis=0), 1e-9)
         e = np.abs(tau_g - tau_o).max(axis=0) / den
         split |= diverged & (e > np.where(regular, 1e-8, 1e-4))  # torques differ *and* the generators explain it
-        # (an event that makes a Cartesian generator re-plan in mid-motion — new limits, half of it re-initialised by
-        # a force-space change — puts every moving robot on that threshold at once: 15-40 % of a batch have been
-        # seen to take the other branch, those where libm and ocml differ in the last bit of a sine)
+        # (since the bit-reproducible trigonometry and initialisation pose of round 2 — include/sai2b_detmath.h,
+        # sai2b_detfk.h, shared by product and oracle — no robot takes another planner branch: the bound is 0)
         _SPLIT_STATS[seed] = (int(split.sum()), B)
         assert split.sum() <= _SPLIT_BOUND(B), (seed, name, log[-6:], np.nonzero(split)[0])  # several such events in one run add up
         e[split] = 0
