@@ -171,13 +171,15 @@ def main():
     def window():
         """EXACTLY args.steps steps between two barriers (ctx stream drained + device synchronize + all ranks arrived)"""
         barrier()
-        t0 = time.perf_counter()
         ev0.record(stream)
+        t0 = time.perf_counter()
         for _ in range(args.steps):
             ctrl.tick(want_output=False)
         ev1.record(stream)
-        barrier()
-        return time.perf_counter() - t0, ev0.elapsed_time(ev1) / args.steps  # wall; HIP events on the ctx stream
+        ctrl.synchronize()  # the stream every launch of the window went to has drained: the K steps are done
+        t1 = time.perf_counter()
+        barrier()  # device synchronize + all ranks arrived (nothing left to wait for on this rank)
+        return t1 - t0, ev0.elapsed_time(ev1) / args.steps  # wall; HIP events on the ctx stream
 
     # A window of K steps is K x ~30 us: with the default K that is a few ms, with --steps 20 well under one, and a
     # single such window measures the clock ramp and one host wake-up more than the kernel. When the window is shorter

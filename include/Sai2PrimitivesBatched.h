@@ -18,9 +18,15 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
+#include <exception>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "sai2b.h"
@@ -944,6 +950,200 @@ inline Batch MotionForceTask::getSigmaValues() const {
 	detail::check(ctx(), sai2b_get_mft_singularity(ctx(), index(), out.data(), nullptr, nullptr));
 	return out;
 }
+// A batch sharded over the GPUs of a node (BASELINE C5: "8-GPU runs simply shard the batch, no RCCL"):
+// one context and ONE HOST THREAD per device, contiguous slices of the batch (the remainder spread over the low
+// shards, as sai2-primitives-perso_amd/sharding.py:shard_bounds), every call scattered to the shards by index, run
+// concurrently and gathered by index. There is no exchange between shards — robots are independent — so no collective
+// and nothing of RCCL. The reference has no counterpart (one robot, one control thread: examples/05-...cpp:138-196);
+// the method names are the RobotController's. Arrays are [C][B_total], SoA like everywhere else. `devices` lists the
+// HIP device of each shard (empty: one shard per visible device); the same device may appear more than once.
+class ShardedRobotController {
+public:
+	ShardedRobotController(const sai2b_robot_model& model, const std::vector<sai2b_task_config>& tasks, const int total_batch,
+						   std::vector<int> devices = {})
+		: _dof(model.dof), _total(total_batch), _cfgs(tasks) {
+		if (devices.empty())
+			for (int d = 0; d < sai2b_device_count(); d++) devices.push_back(d);
+		if (devices.empty()) throw std::runtime_error("ShardedRobotController: no HIP device visible");
+		if (tasks.empty()) throw std::invalid_argument("RobotController must have at least one task");
+		const int G = (int)devices.size();
+		if (total_batch < G) throw std::invalid_argument("ShardedRobotController: fewer robots than shards");
+		_shards.resize(G);
+		for (int s = 0; s < G; s++) {
+			const int base = total_batch / G, rem = total_batch % G;
+			_shards[s].lo = s * base + std::min(s, rem);
+			_shards[s].hi = _shards[s].lo + base + (s < rem ? 1 : 0);
+			_shards[s].device = devices[s];
+		}
+		for (int s = 0; s < G; s++) _shards[s].worker = std::thread([this, s] { workerLoop(s); });
+		try {
+			forAll([&](Shard& sh) {
+				sh.ctx = sai2b_create(&model, _cfgs.data(), (int)_cfgs.size(), sh.hi - sh.lo, sh.device);
+				if (!sh.ctx) {
+					const std::string msg = sai2b_last_error(nullptr);
+					if (msg.find("HIP") != std::string::npos || msg.find("hip") != std::string::npos) throw std::runtime_error(msg);
+					throw std::invalid_argument(msg);
+				}
+			});
+		} catch (...) {
+			shutdown();
+			throw;
+		}
+	}
+	~ShardedRobotController() { shutdown(); }
+	ShardedRobotController(const ShardedRobotController&) = delete;
+	ShardedRobotController& operator=(const ShardedRobotController&) = delete;
+
+	int batch() const { return _total; }
+	int shards() const { return (int)_shards.size(); }
+	std::pair<int, int> shardBounds(const int s) const { return {_shards.at(s).lo, _shards.at(s).hi}; }
+	sai2b_ctx* ctx(const int s) { return _shards.at(s).ctx; }
+
+	// Sai2Model::setQ / setDq + updateModel() of every robot: [dof][B_total] each (dq may be empty: unchanged)
+	void setState(const Batch& q, const Batch& dq) {
+		rows(q, _dof, "q");
+		if (!dq.empty()) rows(dq, _dof, "dq");
+		forAll([&](Shard& sh) {
+			const Batch qs = slice(q, _dof, sh), dqs = dq.empty() ? Batch() : slice(dq, _dof, sh);
+			detail::check(sh.ctx, sai2b_set_state(sh.ctx, qs.data(), dqs.empty() ? nullptr : dqs.data(), 0));
+		});
+	}
+	void reinitializeTasks() { forAll([](Shard& sh) { detail::check(sh.ctx, sai2b_reinitialize(sh.ctx)); }); }
+	void enableGravityCompensation(const bool on) {
+		forAll([on](Shard& sh) { detail::check(sh.ctx, sai2b_enable_gravity_compensation(sh.ctx, on)); });
+	}
+	// JointTask::setGoalPosition / Velocity / Acceleration of task `task`: [task_dof][B_total], empty = leave as is
+	void setJointTaskGoals(const int task, const Batch& q, const Batch& dq = {}, const Batch& ddq = {}) {
+		const int k0 = _cfgs.at(task).task_dof;
+		for (const Batch* v : {&q, &dq, &ddq})
+			if (!v->empty()) rows(*v, k0, "joint task goal");
+		forAll([&](Shard& sh) {
+			const Batch a = slice(q, k0, sh), b = slice(dq, k0, sh), c = slice(ddq, k0, sh);
+			detail::check(sh.ctx, sai2b_set_jt_goals(sh.ctx, task, ptr(a), ptr(b), ptr(c), 0));
+		});
+	}
+	// MotionForceTask goal setters of task `task`: position [3], orientation [9] (row-major), linear / angular velocity and
+	// acceleration [3] each, all x B_total; empty = leave as is
+	void setMotionForceTaskGoals(const int task, const Batch& pos, const Batch& rot = {}, const Batch& lin_vel = {}, const Batch& ang_vel = {},
+								 const Batch& lin_acc = {}, const Batch& ang_acc = {}) {
+		const Batch* v[6] = {&pos, &rot, &lin_vel, &ang_vel, &lin_acc, &ang_acc};
+		for (int i = 0; i < 6; i++)
+			if (!v[i]->empty()) rows(*v[i], i == 1 ? 9 : 3, "motion force task goal");
+		forAll([&](Shard& sh) {
+			Batch s[6];
+			for (int i = 0; i < 6; i++) s[i] = slice(*v[i], i == 1 ? 9 : 3, sh);
+			detail::check(sh.ctx, sai2b_set_mft_goals(sh.ctx, task, ptr(s[0]), ptr(s[1]), ptr(s[2]), ptr(s[3]), ptr(s[4]), ptr(s[5]), 0));
+		});
+	}
+	// a run-time setter of the reference applied to every shard (gains, decoupling, force space, OTG switches ...)
+	void updateTaskConfig(const int task, const sai2b_task_config& cfg) {
+		_cfgs.at(task) = cfg;
+		forAll([&](Shard& sh) { detail::check(sh.ctx, sai2b_update_task_config(sh.ctx, task, &cfg)); });
+	}
+	void updateControllerTaskModels() { forAll([](Shard& sh) { detail::check(sh.ctx, sai2b_update_task_models(sh.ctx)); }); }
+	// RobotController::computeControlTorques of every robot: [dof][B_total]
+	Batch computeControlTorques() {
+		return gatherTau([](Shard& sh, double* tau) { detail::check(sh.ctx, sai2b_compute_control_torques(sh.ctx, tau, 0)); });
+	}
+	// updateControllerTaskModels() + computeControlTorques() fused
+	Batch tick() {
+		return gatherTau([](Shard& sh, double* tau) { detail::check(sh.ctx, sai2b_tick(sh.ctx, tau, 0)); });
+	}
+	// ticks with the torques left on the devices (a device-resident consumer, e.g. sai2b_sim_step(ctx(s), NULL, ...))
+	void tickOnDevice() { forAll([](Shard& sh) { detail::check(sh.ctx, sai2b_tick(sh.ctx, nullptr, 0)); }); }
+	void synchronize() { forAll([](Shard& sh) { detail::check(sh.ctx, sai2b_synchronize(sh.ctx)); }); }
+
+private:
+	struct Shard {
+		int lo = 0, hi = 0, device = 0;
+		sai2b_ctx* ctx = nullptr;
+		std::thread worker;
+		std::function<void(Shard&)> job;  // guarded by _m
+		bool has_job = false;
+		std::exception_ptr error;
+	};
+	static const double* ptr(const Batch& b) { return b.empty() ? nullptr : b.data(); }
+	void rows(const Batch& v, const int r, const char* what) const {
+		if (v.size() != (size_t)r * _total) throw std::invalid_argument(std::string(what) + " size not consistent with the sharded batch");
+	}
+	// rows [C][lo, hi) of a [C][B_total] array as a contiguous [C][hi - lo] one
+	Batch slice(const Batch& v, const int r, const Shard& sh) const {
+		if (v.empty()) return {};
+		const size_t n = (size_t)(sh.hi - sh.lo);
+		Batch out((size_t)r * n);
+		for (int c = 0; c < r; c++) std::copy(v.begin() + (size_t)c * _total + sh.lo, v.begin() + (size_t)c * _total + sh.hi, out.begin() + c * n);
+		return out;
+	}
+	template <class F> Batch gatherTau(F f) {
+		Batch tau((size_t)_dof * _total);
+		forAll([&](Shard& sh) {
+			const size_t n = (size_t)(sh.hi - sh.lo);
+			Batch part((size_t)_dof * n);
+			f(sh, part.data());
+			for (int c = 0; c < _dof; c++) std::copy(part.begin() + c * n, part.begin() + (c + 1) * n, tau.begin() + (size_t)c * _total + sh.lo);
+		});
+		return tau;
+	}
+	// hand the same job to every shard's thread, wait for all, rethrow the first failure
+	void forAll(const std::function<void(Shard&)>& job) {
+		{
+			std::lock_guard<std::mutex> g(_m);
+			for (Shard& sh : _shards) sh.job = job, sh.has_job = true, sh.error = nullptr;
+			_pending = (int)_shards.size();
+		}
+		_cv.notify_all();
+		std::unique_lock<std::mutex> g(_m);
+		_done.wait(g, [this] { return _pending == 0; });
+		for (Shard& sh : _shards)
+			if (sh.error) std::rethrow_exception(sh.error);
+	}
+	void workerLoop(const int s) {
+		Shard& sh = _shards[s];
+		for (;;) {
+			std::function<void(Shard&)> job;
+			{
+				std::unique_lock<std::mutex> g(_m);
+				_cv.wait(g, [&] { return sh.has_job || _stop; });
+				if (_stop && !sh.has_job) return;
+				job = sh.job;
+				sh.has_job = false;
+			}
+			std::exception_ptr err;
+			try {
+				job(sh);
+			} catch (...) {
+				err = std::current_exception();
+			}
+			{
+				std::lock_guard<std::mutex> g(_m);
+				sh.error = err;
+				if (--_pending == 0) _done.notify_all();
+			}
+		}
+	}
+	void shutdown() {
+		{
+			std::lock_guard<std::mutex> g(_m);
+			_stop = true;
+		}
+		_cv.notify_all();
+		for (Shard& sh : _shards)
+			if (sh.worker.joinable()) sh.worker.join();
+		for (Shard& sh : _shards) {
+			if (sh.ctx) sai2b_destroy(sh.ctx);
+			sh.ctx = nullptr;
+		}
+	}
+
+	int _dof, _total;
+	std::vector<sai2b_task_config> _cfgs;
+	std::vector<Shard> _shards;
+	std::mutex _m;
+	std::condition_variable _cv, _done;
+	int _pending = 0;
+	bool _stop = false;
+};
+
 // Stands in for Sai2Simulation in the examples' loops (examples/05-...cpp:215-236: setJointTorques,
 // integrate, getJointPositions, getJointVelocities): rigid-body dynamics of the whole batch with the
 // state resident on the device (sai2b_sim_step). Without setJointTorques, integrate() consumes the

@@ -456,6 +456,10 @@ int sai2b_get_model(sai2b_ctx* ctx, int task, double* M, double* J, double* pos,
  * declines are not served): a profiling call, not part of a control loop. */
 int sai2b_profile_tick(sai2b_ctx* ctx, int steps, double* first_kernel_ms, double* second_kernel_ms);
 
+/* HIP devices visible to this process (0 when there is none or the runtime fails): what a host that shards a batch
+ * over the GPUs of a node creates one context each for (Sai2PrimitivesBatched.h: ShardedRobotController) */
+int sai2b_device_count(void);
+
 /* How many robots of the last tick the SVD-free kernel handed to the generic (Jacobi-SVD) kernel: those
  * inside or leaving a singularity-blending region (SingularityHandler.cpp:66-160). 0 for hierarchies
  * that run the generic kernel for every robot. Waits for the ctx stream. */

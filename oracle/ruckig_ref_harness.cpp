@@ -56,6 +56,12 @@ void rref_set_limits(void* hh, const double* vmax, const double* amax) {
 	}
 }
 
+/* a finite max_jerk selects ruckig's third-order (jerk-limited) position interface */
+void rref_set_jerk(void* hh, const double* jmax) {
+	Handle* h = (Handle*)hh;
+	for (size_t i = 0; i < h->input.degrees_of_freedom; ++i) h->input.max_jerk[i] = jmax[i];
+}
+
 void rref_set_current(void* hh, const double* p, const double* v, const double* a) {
 	Handle* h = (Handle*)hh;
 	for (size_t i = 0; i < h->input.degrees_of_freedom; ++i) {
@@ -119,6 +125,45 @@ int rref_calculate_and_sample(int dofs, int sync, const double* cp, const double
 		in.max_velocity[i] = vmax[i];
 		in.max_acceleration[i] = amax[i];
 		in.max_jerk[i] = std::numeric_limits<double>::infinity();
+	}
+	const Result r = otg.calculate(in, traj);
+	if (r != Result::Working) {
+		*duration = 0.0;
+		return (int)r;
+	}
+	*duration = traj.get_duration();
+	std::vector<double> p(n), v(n), a(n);
+	for (int k = 0; k < n_times; ++k) {
+		traj.at_time(times[k], p, v, a);
+		for (size_t i = 0; i < n; ++i) {
+			out_p[k * n + i] = p[i];
+			out_v[k * n + i] = v[i];
+			out_a[k * n + i] = a[i];
+		}
+	}
+	return (int)r;
+}
+
+/* the same one-shot calculation with a max_jerk vector (the jerk-limited interface the wrappers select with
+ * OTG_joints::setMaxJerk, OTG_joints.cpp:73-86) */
+int rref_calculate_and_sample_jerk(int dofs, int sync, const double* cp, const double* cv, const double* ca, const double* tp,
+								   const double* tv, const double* vmax, const double* amax, const double* jmax,
+								   double* duration, int n_times, const double* times, double* out_p, double* out_v,
+								   double* out_a) {
+	const size_t n = (size_t)dofs;
+	Ruckig<DynamicDOFs> otg(n, 0.001);
+	InputParameter<DynamicDOFs> in(n);
+	Trajectory<DynamicDOFs> traj(n);
+	in.synchronization = (Synchronization)sync;
+	for (size_t i = 0; i < n; ++i) {
+		in.current_position[i] = cp[i];
+		in.current_velocity[i] = cv[i];
+		in.current_acceleration[i] = ca[i];
+		in.target_position[i] = tp[i];
+		in.target_velocity[i] = tv[i];
+		in.max_velocity[i] = vmax[i];
+		in.max_acceleration[i] = amax[i];
+		in.max_jerk[i] = jmax[i];
 	}
 	const Result r = otg.calculate(in, traj);
 	if (r != Result::Working) {

@@ -229,6 +229,7 @@ EXPORTS = [
     "sai2b_get_otg_status",
     "sai2b_get_model",
     "sai2b_profile_tick",
+    "sai2b_device_count",
     "sai2b_get_fallback_count",
     "sai2b_counters",
 ]

@@ -1671,6 +1671,11 @@ extern "C" int sai2b_get_fallback_count(sai2b_ctx* ctx, int* robots) {
 	return SAI2B_OK;
 }
 
+extern "C" int sai2b_device_count(void) {
+	int n = 0;
+	return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 extern "C" int sai2b_counters(const sai2b_ctx* ctx, long long* launches, long long* ticks) {
 	if (!ctx) return SAI2B_INVALID_ARGUMENT;
 	if (launches) *launches = ctx->launches;

@@ -37,7 +37,7 @@ namespace otg {
 #define SAI2B_OTG_MAXD 7  // DoFs of the largest generator; the 8-joint build of the library sets 8 (sai2b_params.h: OTG_MD)
 #endif
 constexpr int MAXD = SAI2B_OTG_MAXD;
-constexpr int WORKING = 0, FINISHED = 1, ERR_INVALID_INPUT = -100, ERR_TRAJECTORY_DURATION = -101,
+constexpr int WORKING = 0, FINISHED = 1, ERR_INVALID_INPUT = -100, ERR_TRAJECTORY_DURATION = -101, ERR_ZERO_LIMITS = -104,
 			  ERR_EXECUTION_TIME = -110, ERR_SYNCHRONIZATION = -111;
 constexpr double EPS = 2.220446049250313e-16;
 
@@ -553,7 +553,15 @@ struct Gen {
 	double ref[9], goal_R[9], goal_w[3];
 };
 
-SAI2B_HD bool input_differs(const Gen& g, int n, double epoch) {
+SAI2B_HD int plan(Gen& g, int n, const double (&vmax)[MAXD], const double (&amax)[MAXD]) {
+	if (!validate(g.in, n, vmax, amax)) return ERR_INVALID_INPUT;
+	Traj tr;
+	const int result = calculate(g.in, n, vmax, amax, tr);
+	if (result == WORKING) g.traj = tr;
+	return result;
+}
+
+template <class G> SAI2B_HD bool input_differs(const G& g, int n, double epoch) {
 	bool diff = g.ci_epoch != epoch;
 #pragma unroll
 	for (int d = 0; d < MAXD; d++)
@@ -563,32 +571,34 @@ SAI2B_HD bool input_differs(const Gen& g, int n, double epoch) {
 	return diff;
 }
 
+// The wrappers below are written once for both generators: Gen (acceleration-limited, this file) and otg3::Gen
+// (jerk-limited, sai2b_otg3_core.hpp). What differs is reached through two overloaded hooks found by argument type:
+// sample_dof(g, d) = Trajectory::at_time of DoF d at g.time; plan(g, n, vmax, amax) = validate + calculate into g.traj.
+SAI2B_HD void sample_dof(Gen& g, int d) { at_time(g.traj.dof[d], g.traj.prof[d], g.traj.duration, g.time, g.np[d], g.nv[d], g.na[d]); }
+
 // Ruckig::update, second half (ruckig.hpp:205-215): advance along the stored trajectory
-SAI2B_HD int ruckig_sample(Gen& g, int n, double dt, int result) {
+template <class G> SAI2B_HD int ruckig_sample(G& g, int n, double dt, int result) {
 	g.time += dt;
 #pragma unroll
 	for (int d = 0; d < MAXD; d++)
 		if (d < n) {
-			at_time(g.traj.dof[d], g.traj.prof[d], g.traj.duration, g.time, g.np[d], g.nv[d], g.na[d]);
+			sample_dof(g, d);
 			g.ci.cp[d] = g.np[d], g.ci.cv[d] = g.nv[d], g.ci.ca[d] = g.na[d];
 		}
 	if (g.time > g.traj.duration) return FINISHED;
 	return result;
 }
 // does Ruckig::update have to calculate a new trajectory (ruckig.hpp:194)?
-SAI2B_HD bool needs_plan(const Gen& g, int n, double epoch) { return input_differs(g, n, epoch) || !g.ci_init; }
+template <class G> SAI2B_HD bool needs_plan(const G& g, int n, double epoch) { return input_differs(g, n, epoch) || !g.ci_init; }
 
 // Ruckig::update (ruckig.hpp:180-216)
-SAI2B_HD int ruckig_update(Gen& g, int n, double dt, const double (&vmax)[MAXD], const double (&amax)[MAXD],
+template <class G> SAI2B_HD int ruckig_update(G& g, int n, double dt, const double (&vmax)[MAXD], const double (&amax)[MAXD],
 						   double epoch) {
 	int result = WORKING;
 	g.replanned = 0;
 	if (needs_plan(g, n, epoch)) {
-		if (!validate(g.in, n, vmax, amax)) return ERR_INVALID_INPUT;
-		Traj tr;
-		result = calculate(g.in, n, vmax, amax, tr);
+		result = plan(g, n, vmax, amax);
 		if (result != WORKING) return result;  // the stored trajectory stays (the wrapper restores it)
-		g.traj = tr;
 		g.ci = g.in;
 		g.ci_epoch = epoch;
 		g.ci_init = 1;
@@ -598,7 +608,7 @@ SAI2B_HD int ruckig_update(Gen& g, int n, double dt, const double (&vmax)[MAXD],
 	return ruckig_sample(g, n, dt, result);
 }
 
-SAI2B_HD void pass_to_input(Gen& g, int n) {
+template <class G> SAI2B_HD void pass_to_input(G& g, int n) {
 #pragma unroll
 	for (int d = 0; d < MAXD; d++)
 		if (d < n) g.in.cp[d] = g.np[d], g.in.cv[d] = g.nv[d], g.in.ca[d] = g.na[d];
@@ -618,7 +628,7 @@ SAI2B_HD bool approx_range(const double (&a)[MAXD], const double (&b)[MAXD], int
 }
 
 // ---- OTG_joints (OTG_joints.cpp) ----
-SAI2B_HD void joints_set_goal(Gen& g, int n, const double (&gp)[MAXD], const double (&gv)[MAXD]) {
+template <class G> SAI2B_HD void joints_set_goal(G& g, int n, const double (&gp)[MAXD], const double (&gv)[MAXD]) {
 	if (g.target_set && approx_range(gp, g.in.tp, 0, n, 1e-12) && approx_range(gv, g.in.tv, 0, n, 1e-12)) return;
 	g.goal_reached = 0;
 	g.target_set = 1;
@@ -626,7 +636,7 @@ SAI2B_HD void joints_set_goal(Gen& g, int n, const double (&gp)[MAXD], const dou
 	for (int d = 0; d < MAXD; d++)
 		if (d < n) g.in.tp[d] = gp[d], g.in.tv[d] = gv[d];
 }
-SAI2B_HD void joints_reinitialize(Gen& g, int n, const double (&x0)[MAXD]) {
+template <class G> SAI2B_HD void joints_reinitialize(G& g, int n, const double (&x0)[MAXD]) {
 	const double zeros[MAXD] = {0, 0, 0, 0, 0, 0, 0};
 	joints_set_goal(g, n, x0, zeros);
 #pragma unroll
@@ -638,16 +648,16 @@ SAI2B_HD void joints_reinitialize(Gen& g, int n, const double (&x0)[MAXD]) {
 struct Prev {
 	double p[MAXD], v[MAXD], a[MAXD];
 };
-SAI2B_HD void save_prev(const Gen& g, Prev& pv) {
+template <class G> SAI2B_HD void save_prev(const G& g, Prev& pv) {
 #pragma unroll
 	for (int d = 0; d < MAXD; d++) pv.p[d] = g.np[d], pv.v[d] = g.nv[d], pv.a[d] = g.na[d];
 }
-SAI2B_HD void on_error(Gen& g, int n, const Prev& pv) {	 // OTG_joints.cpp:141-149, OTG_6dof_cartesian.cpp:215-223
+template <class G> SAI2B_HD void on_error(G& g, int n, const Prev& pv) {	 // OTG_joints.cpp:141-149, OTG_6dof_cartesian.cpp:215-223
 #pragma unroll
 	for (int d = 0; d < MAXD; d++)
 		if (d < n) g.np[d] = pv.p[d], g.nv[d] = pv.v[d], g.na[d] = pv.a[d], g.in.cv[d] = 0, g.in.ca[d] = 0;
 }
-SAI2B_HD double velocity_norm(const Gen& g, int n) {
+template <class G> SAI2B_HD double velocity_norm(const G& g, int n) {
 	double nrm = 0;
 #pragma unroll
 	for (int d = 0; d < MAXD; d++)
@@ -658,7 +668,7 @@ SAI2B_HD double velocity_norm(const Gen& g, int n) {
 // Finished-with-velocity branch calls setGoalPosition with a member that is never assigned (:129),
 // which throws in the reference; it does what the Cartesian wrapper does there (keep the target
 // position, zero the target velocity).
-SAI2B_HD void joints_finish(Gen& g, int n, const Prev& pv) {
+template <class G> SAI2B_HD void joints_finish(G& g, int n, const Prev& pv) {
 	if (g.result == FINISHED) {
 		if (velocity_norm(g, n) < 1e-3) {
 			g.goal_reached = 1;
@@ -676,7 +686,7 @@ SAI2B_HD void joints_finish(Gen& g, int n, const Prev& pv) {
 	}
 }
 // OTG_joints::update (OTG_joints.cpp:118-150)
-SAI2B_HD void joints_update(Gen& g, int n, double dt, const double (&vmax)[MAXD], const double (&amax)[MAXD],
+template <class G> SAI2B_HD void joints_update(G& g, int n, double dt, const double (&vmax)[MAXD], const double (&amax)[MAXD],
 							double epoch) {
 	if (g.goal_reached) return;
 	Prev pv;
@@ -772,7 +782,7 @@ SAI2B_HD void vec_to_rot(double x, double y, double z, double* R) {
 
 // ---- OTG_6dof_cartesian (OTG_6dof_cartesian.cpp); DoF 0-2 position, 3-5 rotation vector in
 // the reference frame; target_set bit 0 = position target set, bit 1 = orientation goal set ----
-SAI2B_HD void cart_next_orientation(const Gen& g, double* rot) {
+template <class G> SAI2B_HD void cart_next_orientation(const G& g, double* rot) {
 	double local[9];
 	vec_to_rot(g.np[3], g.np[4], g.np[5], local);
 	mat3_mul(g.ref, local, rot);
@@ -788,7 +798,7 @@ SAI2B_HD bool approx9(const double* a, const double* b, int n, double prec) {
 		}
 	return dd <= prec * prec * (na < nb ? na : nb);
 }
-SAI2B_HD void cart_set_goal_position(Gen& g, const double* gp, const double* gv) {
+template <class G> SAI2B_HD void cart_set_goal_position(G& g, const double* gp, const double* gv) {
 	const double p7[MAXD] = {gp[0], gp[1], gp[2], 0, 0, 0, 0}, v7[MAXD] = {gv[0], gv[1], gv[2], 0, 0, 0, 0};
 	if ((g.target_set & 1) && approx_range(p7, g.in.tp, 0, 3, 1e-3) && approx_range(v7, g.in.tv, 0, 3, 1e-3)) return;
 	g.goal_reached = 0;
@@ -796,7 +806,7 @@ SAI2B_HD void cart_set_goal_position(Gen& g, const double* gp, const double* gv)
 #pragma unroll
 	for (int i = 0; i < 3; i++) g.in.tp[i] = gp[i], g.in.tv[i] = gv[i];
 }
-SAI2B_HD void cart_set_goal_orientation(Gen& g, const double* gR, const double* gw) {
+template <class G> SAI2B_HD void cart_set_goal_orientation(G& g, const double* gR, const double* gw) {
 	if ((g.target_set & 2) && approx9(g.goal_R, gR, 9, 1e-3) && approx9(g.goal_w, gw, 3, 1e-3)) return;
 	g.goal_reached = 0;
 	g.target_set |= 2;
@@ -819,7 +829,7 @@ SAI2B_HD void cart_set_goal_orientation(Gen& g, const double* gR, const double* 
 	mat3_tvec(g.ref, g.goal_w, tmp);
 	g.in.tv[3] = tmp[0], g.in.tv[4] = tmp[1], g.in.tv[5] = tmp[2];
 }
-SAI2B_HD void cart_reinitialize(Gen& g, const double* pos, const double* rot) {
+template <class G> SAI2B_HD void cart_reinitialize(G& g, const double* pos, const double* rot) {
 	const double zeros[3] = {0, 0, 0};
 	cart_set_goal_position(g, pos, zeros);
 	cart_set_goal_orientation(g, rot, zeros);
@@ -830,7 +840,7 @@ SAI2B_HD void cart_reinitialize(Gen& g, const double* pos, const double* rot) {
 	}
 }
 // reInitializeLinear / reInitializeAngular (OTG_6dof_cartesian.cpp:60-83)
-SAI2B_HD void cart_reinitialize_linear(Gen& g, const double* pos) {
+template <class G> SAI2B_HD void cart_reinitialize_linear(G& g, const double* pos) {
 	const double zeros[3] = {0, 0, 0};
 	cart_set_goal_position(g, pos, zeros);
 #pragma unroll
@@ -839,7 +849,7 @@ SAI2B_HD void cart_reinitialize_linear(Gen& g, const double* pos) {
 		g.np[i] = g.in.tp[i], g.nv[i] = 0, g.na[i] = 0;
 	}
 }
-SAI2B_HD void cart_reinitialize_angular(Gen& g, const double* rot) {
+template <class G> SAI2B_HD void cart_reinitialize_angular(G& g, const double* rot) {
 	const double zeros[3] = {0, 0, 0};
 	cart_set_goal_orientation(g, rot, zeros);
 #pragma unroll
@@ -849,7 +859,7 @@ SAI2B_HD void cart_reinitialize_angular(Gen& g, const double* rot) {
 	}
 }
 // OTG_6dof_cartesian::update after _otg->update() returned g.result (OTG_6dof_cartesian.cpp:194-223)
-SAI2B_HD void cart_finish(Gen& g, const Prev& pv) {
+template <class G> SAI2B_HD void cart_finish(G& g, const Prev& pv) {
 	if (g.result == FINISHED) {
 		if (velocity_norm(g, 6) < 1e-3) {
 			g.goal_reached = 1;
@@ -869,7 +879,7 @@ SAI2B_HD void cart_finish(Gen& g, const Prev& pv) {
 	}
 }
 // OTG_6dof_cartesian::update (OTG_6dof_cartesian.cpp:187-224)
-SAI2B_HD void cart_update(Gen& g, double dt, const double (&vmax)[MAXD], const double (&amax)[MAXD], double epoch) {
+template <class G> SAI2B_HD void cart_update(G& g, double dt, const double (&vmax)[MAXD], const double (&amax)[MAXD], double epoch) {
 	if (g.goal_reached) return;
 	Prev pv;
 	save_prev(g, pv);

@@ -173,6 +173,50 @@ static int tick(int B, const char* path) {
 	return 0;
 }
 
+// The same workload through ShardedRobotController: `shards` contexts on device 0, each with a host thread of its own
+// (on an 8-GPU node: devices = {} gives one shard per GPU). Prints the torques of two ticks.
+static int sharded(int B, const char* path, int shards) {
+	std::ifstream f(path, std::ios::binary);
+	auto rd = [&](size_t rows) {
+		Batch b(rows * (size_t)B);
+		f.read((char*)b.data(), b.size() * sizeof(double));
+		return b;
+	};
+	const Batch q = rd(7), dq = rd(7);
+	// task configurations as the reference's constructors + setters leave them
+	auto robot = std::make_shared<BatchedRobotModel>(B);
+	const double pos[3] = {0, 0, 0.22};
+	auto mft = std::make_shared<MotionForceTask>(robot, 6, pos);
+	mft->disableInternalOtg();
+	auto jt = std::make_shared<JointTask>(robot);
+	jt->disableInternalOtg();
+	ShardedRobotController ctl(robot->model(), {mft->config(), jt->config()}, B, std::vector<int>((size_t)shards, 0));
+	if (ctl.shards() != shards || ctl.batch() != B) return 3;
+	int covered = 0;
+	for (int s = 0; s < shards; s++) {
+		if (ctl.shardBounds(s).first != covered) return 4;
+		covered = ctl.shardBounds(s).second;
+	}
+	if (covered != B) return 5;
+	ctl.setState(q, dq);
+	ctl.reinitializeTasks();
+	const Batch gp = rd(3), gr = rd(9), gv = rd(3), gw = rd(3), ga = rd(3), gal = rd(3);
+	ctl.setMotionForceTaskGoals(0, gp, gr, gv, gw, ga, gal);
+	ctl.setJointTaskGoals(1, rd(7));
+	ctl.updateControllerTaskModels();
+	Batch tau = ctl.computeControlTorques();
+	std::fwrite(tau.data(), sizeof(double), tau.size(), stdout);
+	tau = ctl.tick();
+	std::fwrite(tau.data(), sizeof(double), tau.size(), stdout);
+	bool threw = false;
+	try {
+		ctl.setState(Batch(7 * (size_t)B - 1), {});
+	} catch (const std::invalid_argument&) {
+		threw = true;
+	}
+	return threw ? 0 : 6;
+}
+
 static Batch add(const Batch& a, const Batch& b) {
 	Batch c(a.size());
 	for (size_t i = 0; i < a.size(); i++) c[i] = a[i] + b[i];
@@ -1048,6 +1092,7 @@ int main(int argc, char** argv) {
 		if (argc >= 5 && std::strcmp(argv[1], "example01") == 0) return example01(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 		if (argc >= 2 && std::strcmp(argv[1], "validate") == 0) return validate();
 		if (argc >= 4 && std::strcmp(argv[1], "tick") == 0) return tick(std::atoi(argv[2]), argv[3]);
+		if (argc >= 5 && std::strcmp(argv[1], "sharded") == 0) return sharded(std::atoi(argv[2]), argv[3], std::atoi(argv[4]));
 	} catch (const std::exception& e) {
 		std::fprintf(stderr, "exception: %s\n", e.what());
 		return 2;

@@ -55,6 +55,33 @@ def test_cpp_facade_tick_matches_oracle(facade_bin, tmp_path):
     assert np.abs(q1 - qo).max() < 1e-12 and np.abs(dq1 - vo).max() < 1e-10
 
 
+@pytest.mark.gpu
+def test_cpp_sharded_controller_equals_one_context(facade_bin, tmp_path):
+    """ShardedRobotController (one context + one host thread per shard, contiguous slices, no collective: SURVEY §8(e)):
+    2 and 3 shards on device 0 — an uneven split of 257 robots — give bit for bit the torques of one context of the
+    whole batch, and those of the oracle to 1e-10"""
+    import oracle_lib as ol
+
+    B = 257
+    inp = pkg.workloads.make_inputs(3, B=B, seed=1234)
+    g = inp["mft0"]
+    blob = np.concatenate([inp["q"].ravel(), inp["dq"].ravel(), g["pos"].ravel(), g["rot"].ravel(), g["v"].ravel(), g["w"].ravel(),
+                           g["a"].ravel(), g["alpha"].ravel(), inp["jt1"]["q"].ravel()])
+    path = tmp_path / "in.bin"
+    blob.astype(np.float64).tofile(path)
+    out = {}
+    for shards in (1, 2, 3):
+        r = subprocess.run([facade_bin, "sharded", str(B), str(path), str(shards)], capture_output=True)
+        assert r.returncode == 0, (shards, r.returncode, r.stderr.decode())
+        out[shards] = np.frombuffer(r.stdout, dtype=np.float64).reshape(2, 7, B)
+    assert np.array_equal(out[1], out[2]) and np.array_equal(out[1], out[3])
+    o = ol.Oracle(ol.panda_model(), ol.task_configs(inp["tasks"]), B)
+    ol.load_inputs(o, inp)
+    for k in range(2):
+        ref = o.tick()
+        assert _err(out[2][k], ref) < 1e-10
+
+
 def _err(a, ref):
     return (np.abs(a - ref).max(axis=0) / np.maximum(np.abs(ref).max(axis=0), 1)).max()
 
