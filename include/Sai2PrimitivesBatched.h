@@ -356,8 +356,31 @@ public:
 		_cfg.use_internal_otg = 1, _cfg.internal_otg_jerk_limited = 0;
 		syncConfig();
 	}
-	void enableInternalOtgJerkLimited(const double, const double, const double) {
-		throw std::invalid_argument("the jerk-limited internal OTG (enableInternalOtgJerkLimited) is not implemented in this build");
+	// JointTask.h:295-313, JointTask.cpp:383-406: ruckig's jerk-limited (third-order) interface
+	void enableInternalOtgJerkLimited(const double max_velocity, const double max_acceleration, const double max_jerk) {
+		if (max_velocity <= 0)
+			throw std::invalid_argument("max velocity cannot be 0 or negative in any directions in OTG_joints::setMaxVelocity\n");
+		if (max_acceleration <= 0)
+			throw std::invalid_argument("max acceleration cannot be 0 or negative in any directions in OTG_joints::setMaxAcceleration\n");
+		if (max_jerk <= 0) throw std::invalid_argument("max jerk cannot be 0 or negative in any directions in OTG_joints::setMaxJerk\n");
+		for (int i = 0; i < SAI2B_MAX_DOF; i++)
+			_cfg.otg_max_velocity[i] = max_velocity, _cfg.otg_max_acceleration[i] = max_acceleration, _cfg.otg_max_jerk[i] = max_jerk;
+		_cfg.use_internal_otg = 1, _cfg.internal_otg_jerk_limited = 1;
+		syncConfig();
+	}
+	void enableInternalOtgJerkLimited(const std::vector<double>& max_velocity, const std::vector<double>& max_acceleration,
+									  const std::vector<double>& max_jerk) {
+		if ((int)max_velocity.size() != _cfg.task_dof || (int)max_acceleration.size() != _cfg.task_dof || (int)max_jerk.size() != _cfg.task_dof)
+			throw std::invalid_argument("max velocity, max acceleration or max jerk vector size not consistent with task dof in JointTask::enableInternalOtgJerkLimited\n");
+		for (int i = 0; i < _cfg.task_dof; i++) {
+			if (max_velocity[i] <= 0) throw std::invalid_argument("max velocity cannot be 0 or negative in any directions in OTG_joints::setMaxVelocity\n");
+			if (max_acceleration[i] <= 0) throw std::invalid_argument("max acceleration cannot be 0 or negative in any directions in OTG_joints::setMaxAcceleration\n");
+			if (max_jerk[i] <= 0) throw std::invalid_argument("max jerk cannot be 0 or negative in any directions in OTG_joints::setMaxJerk\n");
+		}
+		for (int i = 0; i < _cfg.task_dof; i++)
+			_cfg.otg_max_velocity[i] = max_velocity[i], _cfg.otg_max_acceleration[i] = max_acceleration[i], _cfg.otg_max_jerk[i] = max_jerk[i];
+		_cfg.use_internal_otg = 1, _cfg.internal_otg_jerk_limited = 1;
+		syncConfig();
 	}
 	void disableInternalOtg() {
 		_cfg.use_internal_otg = 0;
@@ -370,7 +393,7 @@ public:
 	public:
 		explicit InternalOtg(const JointTask* t) : _t(t) {}
 		std::vector<bool> isGoalReached() const { return _t->otgGoalReached(); }
-		bool getJerkLimitEnabled() const { return false; }
+		bool getJerkLimitEnabled() const { return _t->config().internal_otg_jerk_limited != 0; }
 		Batch getNextPosition() const { return _t->getDesiredPosition(); }
 		Batch getNextVelocity() const { return _t->getDesiredVelocity(); }
 		Batch getNextAcceleration() const { return _t->getDesiredAcceleration(); }
@@ -566,8 +589,20 @@ public:
 		_cfg.use_internal_otg = 1, _cfg.internal_otg_jerk_limited = 0;
 		syncConfig();
 	}
-	void enableInternalOtgJerkLimited(const double, const double, const double, const double, const double, const double) {
-		throw std::invalid_argument("the jerk-limited internal OTG (enableInternalOtgJerkLimited) is not implemented in this build");
+	// MotionForceTask.h:416-421, MotionForceTask.cpp:525-538: ruckig's jerk-limited (third-order) interface
+	void enableInternalOtgJerkLimited(const double max_linear_velocity, const double max_linear_acceleration, const double max_linear_jerk,
+									  const double max_angular_velocity, const double max_angular_acceleration, const double max_angular_jerk) {
+		if (max_linear_velocity <= 0 || max_angular_velocity <= 0)
+			throw std::invalid_argument("max velocity set to 0 or negative value in some directions in OTG_6dof_cartesian::setMaxLinearVelocity\n");
+		if (max_linear_acceleration <= 0 || max_angular_acceleration <= 0)
+			throw std::invalid_argument("max acceleration set to 0 or negative value in some directions in OTG_6dof_cartesian::setMaxLinearAcceleration\n");
+		if (max_linear_jerk <= 0 || max_angular_jerk <= 0)
+			throw std::invalid_argument("max jerk set to 0 or negative value in some directions in OTG_6dof_cartesian::setMaxJerk\n");
+		_cfg.otg_max_linear_velocity = max_linear_velocity, _cfg.otg_max_linear_acceleration = max_linear_acceleration;
+		_cfg.otg_max_angular_velocity = max_angular_velocity, _cfg.otg_max_angular_acceleration = max_angular_acceleration;
+		_cfg.otg_max_linear_jerk = max_linear_jerk, _cfg.otg_max_angular_jerk = max_angular_jerk;
+		_cfg.use_internal_otg = 1, _cfg.internal_otg_jerk_limited = 1;
+		syncConfig();
 	}
 	void disableInternalOtg() {
 		_cfg.use_internal_otg = 0;
@@ -580,7 +615,7 @@ public:
 	public:
 		explicit InternalOtg(const MotionForceTask* t) : _t(t) {}
 		std::vector<bool> isGoalReached() const { return _t->otgGoalReached(); }
-		bool getJerkLimitEnabled() const { return false; }
+		bool getJerkLimitEnabled() const { return _t->config().internal_otg_jerk_limited != 0; }
 		Batch getNextPosition() const { return _t->getDesiredPosition(); }
 		Batch getNextOrientation() const { return _t->getDesiredOrientation(); }
 		Batch getNextLinearVelocity() const { return _t->getDesiredLinearVelocity(); }

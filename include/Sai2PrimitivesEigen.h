@@ -382,7 +382,10 @@ public:
 		_t->enableInternalOtgAccelerationLimited(max_velocity, max_acceleration);
 	}
 	void enableInternalOtgJerkLimited(const double max_velocity, const double max_acceleration, const double max_jerk) {
-		_t->enableInternalOtgJerkLimited(max_velocity, max_acceleration, max_jerk);	 // refused by this build
+		_t->enableInternalOtgJerkLimited(max_velocity, max_acceleration, max_jerk);
+	}
+	void enableInternalOtgJerkLimited(const VectorXd& max_velocity, const VectorXd& max_acceleration, const VectorXd& max_jerk) {
+		_t->enableInternalOtgJerkLimited(D_::batch_of(max_velocity), D_::batch_of(max_acceleration), D_::batch_of(max_jerk));
 	}
 	void disableInternalOtg() { _t->disableInternalOtg(); }
 	bool getInternalOtgEnabled() const { return _t->getInternalOtgEnabled(); }
@@ -530,7 +533,7 @@ public:
 		_t->enableInternalOtgAccelerationLimited(max_linear_velelocity, max_linear_acceleration, max_angular_velocity, max_angular_acceleration);
 	}
 	void enableInternalOtgJerkLimited(const double a, const double b, const double c, const double d, const double e, const double f) {
-		_t->enableInternalOtgJerkLimited(a, b, c, d, e, f);	 // refused by this build
+		_t->enableInternalOtgJerkLimited(a, b, c, d, e, f);
 	}
 	void disableInternalOtg() { _t->disableInternalOtg(); }
 	bool getInternalOtgEnabled() const { return _t->getInternalOtgEnabled(); }

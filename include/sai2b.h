@@ -147,11 +147,16 @@ typedef struct sai2b_task_config {
 	/* ---- internal online trajectory generation (JointTask.h:38-42,294-324;
 	 * MotionForceTask.h:67-74,387-427): on by default, acceleration-limited. The desired state fed
 	 * to the control law is the OTG's next state instead of the goal. ---- */
-	int use_internal_otg;		   /* enableInternalOtgAccelerationLimited / disableInternalOtg */
-	int internal_otg_jerk_limited; /* must be 0: the jerk-limited generator is not implemented */
+	int use_internal_otg;		   /* enableInternalOtgAccelerationLimited / ...JerkLimited / disableInternalOtg */
+	int internal_otg_jerk_limited; /* enableInternalOtgJerkLimited (JointTask.h:295-310, MotionForceTask.h:416): ruckig's
+									* third-order interface with the otg_max_*jerk limits below; switching between the two
+									* modes re-initialises the generator at the task's current pose, as the reference does
+									* (JointTask.cpp:374,399; MotionForceTask.cpp:514,529) */
 	double otg_max_velocity[SAI2B_MAX_DOF], otg_max_acceleration[SAI2B_MAX_DOF]; /* JointTask, per task dof */
 	double otg_max_linear_velocity, otg_max_linear_acceleration;		 /* MotionForceTask */
 	double otg_max_angular_velocity, otg_max_angular_acceleration;
+	double otg_max_jerk[SAI2B_MAX_DOF];							 /* JointTask, per task dof (JointTask.h:42: 10 pi) */
+	double otg_max_linear_jerk, otg_max_angular_jerk;			 /* MotionForceTask (MotionForceTask.h:73-74: 10, 10 pi) */
 
 	/* MotionForceTask::setPosControlGainsUnsafe / setOriControlGainsUnsafe (MotionForceTask.h:283,304;
 	 * MotionForceTask.cpp:630-649) and JointTask::setGainsUnsafe (JointTask.h:256, JointTask.cpp:136-156): nonzero

@@ -20,6 +20,9 @@
 
 #include "../include/sai2b_detmath.h"
 #include <string.h>
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #define EPS DBL_EPSILON
 enum { LIM_ACC0 = 2, LIM_NONE = 7 };
@@ -690,13 +693,87 @@ void otg_at_time(const otg_traj* traj, int n, double time, double* p, double* v,
 	}
 }
 
+/* ---- jerk-limited planning: the reference's own ruckig (oracle/_ref), see otg_oracle.h (3) ---- */
+typedef int (*plan_jerk_fn)(int, int, const double*, const double*, const double*, const double*, const double*, const double*,
+							const double*, const double*, double*, double*);
+static plan_jerk_fn g_plan_jerk;
+static int g_plan_jerk_tried;
+static plan_jerk_fn jerk_planner(void) {
+#pragma omp critical(otg_jerk_planner)
+	if (!g_plan_jerk_tried) {
+		char path[4096];
+		const char* env = getenv("SAI2B_RUCKIG_REF");
+		void* h = NULL;
+		g_plan_jerk_tried = 1;
+		if (env && *env) h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+		if (!h) { /* next to this library: <dir>/_ref/libruckig_ref.so */
+			Dl_info info;
+			if (dladdr((void*)&jerk_planner, &info) && info.dli_fname) {
+				const char* slash = strrchr(info.dli_fname, '/');
+				const int len = slash ? (int)(slash - info.dli_fname) : 0;
+				snprintf(path, sizeof path, "%.*s%s_ref/libruckig_ref.so", len, info.dli_fname, slash ? "/" : "");
+				h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+			}
+		}
+		if (h) g_plan_jerk = (plan_jerk_fn)dlsym(h, "rref_plan_jerk");
+	}
+	return g_plan_jerk;
+}
+int otg_jerk_planner_available(void) { return jerk_planner() != NULL; }
+static int jerk_limited(const otg_input* inp) {
+	int i;
+	for (i = 0; i < inp->n; i++)
+		if (!isinf(inp->jmax[i])) return 1;
+	return 0;
+}
+static void integrate3(double t, double p0, double v0, double a0, double j, double* p, double* v, double* a) { /* utils.hpp:43-49 */
+	*p = p0 + t * (v0 + t * (a0 / 2 + t * j / 6));
+	*v = v0 + t * (a0 + t * j / 2);
+	*a = a0 + t * j;
+}
+/* Trajectory::at_time (trajectory.hpp:65-142) on the numbers of rref_plan_jerk */
+static void at_time3(const otg_traj* traj, int n, double time, double* p, double* v, double* a) {
+	int dof, i;
+	for (dof = 0; dof < n; dof++) {
+		const double* o = traj->prof3[dof];
+		const double brake_duration = o[0], *bt = o + 1, *bj = o + 3, *ba = o + 5, *bv = o + 7, *bp = o + 9;
+		const double *t_sum = o + 11, *j = o + 18, *pa = o + 25, *pv = o + 33, *pp = o + 41;
+		double t_diff = time;
+		if (time >= traj->duration) {
+			integrate3(time - (brake_duration + t_sum[6]), pp[7], pv[7], pa[7], 0.0, &p[dof], &v[dof], &a[dof]);
+			continue;
+		}
+		if (brake_duration > 0) {
+			if (t_diff < brake_duration) {
+				const int index = (t_diff < bt[0]) ? 0 : 1;
+				if (index > 0) t_diff -= bt[index - 1];
+				integrate3(t_diff, bp[index], bv[index], ba[index], bj[index], &p[dof], &v[dof], &a[dof]);
+				continue;
+			}
+			t_diff -= brake_duration;
+		}
+		if (t_diff >= t_sum[6]) {
+			integrate3(t_diff - t_sum[6], pp[7], pv[7], pa[7], 0.0, &p[dof], &v[dof], &a[dof]);
+			continue;
+		}
+		int index = 7;
+		for (i = 0; i < 7; i++)
+			if (t_sum[i] > t_diff) {
+				index = i;
+				break;
+			}
+		if (index > 0) t_diff -= t_sum[index - 1];
+		integrate3(t_diff, pp[index], pv[index], pa[index], j[index], &p[dof], &v[dof], &a[dof]);
+	}
+}
+
 static int input_differs(const otg_input* x, const otg_input* y) {
 	int i;
 	if (x->n != y->n || x->synchronization != y->synchronization) return 1;
 	for (i = 0; i < x->n; i++) {
 		if (!(x->cp[i] == y->cp[i] && x->cv[i] == y->cv[i] && x->ca[i] == y->ca[i] &&
 			  x->tp[i] == y->tp[i] && x->tv[i] == y->tv[i] && x->vmax[i] == y->vmax[i] &&
-			  x->amax[i] == y->amax[i]))
+			  x->amax[i] == y->amax[i] && x->jmax[i] == y->jmax[i]))
 			return 1;
 	}
 	return 0;
@@ -708,16 +785,29 @@ int otg_update(otg_ruckig* otg, const otg_input* inp, otg_output* out) {
 	out->new_calculation = 0;
 	if (input_differs(inp, &otg->current_input) || !otg->current_input_initialized) {
 		/* Ruckig::calculate (ruckig.hpp:171-177) */
-		if (!validate_input(inp)) return OTG_ERROR_INVALID_INPUT;
-		result = otg_calculate(inp, &out->traj);
-		if (result != OTG_WORKING) return result;
+		if (jerk_limited(inp)) { /* the reference's own planner (validation included) */
+			plan_jerk_fn plan = jerk_planner();
+			if (!plan) return OTG_ERROR_NO_REFERENCE_PLANNER;
+			result = plan(inp->n, inp->synchronization, inp->cp, inp->cv, inp->ca, inp->tp, inp->tv, inp->vmax, inp->amax, inp->jmax,
+						  &out->traj.duration, &out->traj.prof3[0][0]);
+			if (result != OTG_WORKING) return result;
+			out->traj.third_order = 1;
+		} else {
+			if (!validate_input(inp)) return OTG_ERROR_INVALID_INPUT;
+			result = otg_calculate(inp, &out->traj);
+			if (result != OTG_WORKING) return result;
+			out->traj.third_order = 0;
+		}
 		otg->current_input = *inp;
 		otg->current_input_initialized = 1;
 		out->time = 0.0;
 		out->new_calculation = 1;
 	}
 	out->time += otg->delta_time;
-	otg_at_time(&out->traj, inp->n, out->time, out->np, out->nv, out->na);
+	if (out->traj.third_order)
+		at_time3(&out->traj, inp->n, out->time, out->np, out->nv, out->na);
+	else
+		otg_at_time(&out->traj, inp->n, out->time, out->np, out->nv, out->na);
 	/* output.pass_to_input(current_input) (ruckig.hpp:209) */
 	for (i = 0; i < inp->n; i++) {
 		otg->current_input.cp[i] = out->np[i];
@@ -789,7 +879,7 @@ void otg_joints_init(otg_joints* o, int dim, const double* x0, double loop_time)
 	o->input.n = dim;
 	o->input.synchronization = OTG_SYNC_PHASE;
 	o->result_value = OTG_FINISHED;
-	for (i = 0; i < dim; i++) o->input.amax[i] = INFINITY;
+	for (i = 0; i < dim; i++) o->input.amax[i] = o->input.jmax[i] = INFINITY;
 	otg_joints_reinitialize(o, x0);
 }
 
@@ -805,7 +895,12 @@ void otg_joints_set_limits(otg_joints* o, const double* vmax, const double* amax
 /* OTG_joints::disableJerkLimits (OTG_joints.cpp:88-91) */
 void otg_joints_disable_jerk_limits(otg_joints* o) {
 	int i;
-	for (i = 0; i < o->dim; i++) o->input.ca[i] = 0;
+	for (i = 0; i < o->dim; i++) o->input.ca[i] = 0, o->input.jmax[i] = INFINITY;
+}
+/* OTG_joints::setMaxJerk (OTG_joints.cpp:73-86) */
+void otg_joints_set_max_jerk(otg_joints* o, const double* max_jerk) {
+	int i;
+	for (i = 0; i < o->dim; i++) o->input.jmax[i] = max_jerk[i];
 }
 
 /* OTG_joints::update (OTG_joints.cpp:118-150) */
@@ -1046,7 +1141,7 @@ void otg_cartesian_init(otg_cartesian* o, const double* pos, const double* rot, 
 	o->input.n = 6;
 	o->input.synchronization = OTG_SYNC_PHASE;
 	o->result_value = OTG_FINISHED;
-	for (i = 0; i < 6; i++) o->input.amax[i] = INFINITY;
+	for (i = 0; i < 6; i++) o->input.amax[i] = o->input.jmax[i] = INFINITY;
 	memcpy(o->reference_frame, rot, 9 * sizeof(double));
 	otg_cartesian_reinitialize(o, pos, rot);
 }
@@ -1059,6 +1154,14 @@ void otg_cartesian_set_limits(otg_cartesian* o, double lv, double la, double av,
 		o->input.amax[i] = la;
 		o->input.vmax[3 + i] = av;
 		o->input.amax[3 + i] = aa;
+	}
+}
+
+void otg_cartesian_set_max_jerk(otg_cartesian* o, double lj, double aj) {
+	int i;
+	for (i = 0; i < 3; i++) {
+		o->input.jmax[i] = (lj > 0 && !isinf(lj)) ? lj : INFINITY;
+		o->input.jmax[3 + i] = (aj > 0 && !isinf(aj)) ? aj : INFINITY;
 	}
 }
 
@@ -1141,11 +1244,16 @@ void* otg_test_create(int dofs, double dt) {
 	int i;
 	h->otg.delta_time = dt;
 	h->input.n = dofs;
-	for (i = 0; i < dofs; i++) h->input.vmax[i] = h->input.amax[i] = 1.0;
+	for (i = 0; i < dofs; i++) h->input.vmax[i] = h->input.amax[i] = 1.0, h->input.jmax[i] = INFINITY;
 	return h;
 }
 void otg_test_destroy(void* h) { free(h); }
 void otg_test_set_synchronization(void* h, int s) { ((otg_test_handle*)h)->input.synchronization = s; }
+void otg_test_set_jerk(void* hh, const double* jmax) { /* finite: the jerk-limited interface (the reference's planner) */
+	otg_test_handle* h = (otg_test_handle*)hh;
+	int i;
+	for (i = 0; i < h->input.n; i++) h->input.jmax[i] = jmax[i];
+}
 void otg_test_set_limits(void* hh, const double* vmax, const double* amax) {
 	otg_test_handle* h = (otg_test_handle*)hh;
 	int i;

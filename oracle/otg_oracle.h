@@ -16,8 +16,12 @@
  * stepped trajectories; committed fixtures tests/golden/otg_*.npz hold the reference's outputs.
  * (2) needs Eigen and cannot be built: "parity unpinned" there, checked by an independent numpy
  * restatement of the wrappers driving the real ruckig core (tests/golden/make_otg_golden.py).
- * The jerk-limited (third-order) interface is not restated (the tasks default to
- * acceleration-limited: JointTask.h:39, MotionForceTask.h:72).
+ * (3) The jerk-limited (third-order) planner is NOT restated: for a generator with a finite max_jerk
+ * (enableInternalOtgJerkLimited: JointTask.cpp:383-406, MotionForceTask.cpp:525-538) otg_update calls the REFERENCE's
+ * own ruckig — rref_plan_jerk of oracle/_ref/libruckig_ref.so, compiled from the reference's sources (Makefile `ref`),
+ * loaded on first use — and samples the trajectory it returns. Stronger than a restatement where it applies: the
+ * oracle's planner there is the reference's code. Without oracle/_ref a jerk-limited generator reports
+ * OTG_ERROR_NO_REFERENCE_PLANNER (tests skip). The restated parts around it stay: Ruckig::update, sampling, wrappers.
  */
 #ifndef OTG_ORACLE_H_
 #define OTG_ORACLE_H_
@@ -36,7 +40,8 @@ enum {
 	OTG_ERROR_INVALID_INPUT = -100,
 	OTG_ERROR_TRAJECTORY_DURATION = -101,
 	OTG_ERROR_EXECUTION_TIME_CALCULATION = -110,
-	OTG_ERROR_SYNCHRONIZATION_CALCULATION = -111
+	OTG_ERROR_SYNCHRONIZATION_CALCULATION = -111,
+	OTG_ERROR_NO_REFERENCE_PLANNER = -900 /* ours: jerk-limited planning needs oracle/_ref/libruckig_ref.so */
 };
 enum { OTG_SYNC_TIME = 0, OTG_SYNC_PHASE = 2 };
 
@@ -59,11 +64,16 @@ typedef struct {
 	double cp[OTG_MAX_DOF], cv[OTG_MAX_DOF], ca[OTG_MAX_DOF];
 	double tp[OTG_MAX_DOF], tv[OTG_MAX_DOF];
 	double vmax[OTG_MAX_DOF], amax[OTG_MAX_DOF];
+	double jmax[OTG_MAX_DOF]; /* INFINITY: acceleration-limited (the default); finite: the jerk-limited interface */
 } otg_input;
 
+/* a third-order profile as the reference's planner returns it (ruckig_ref_harness.cpp: rref_plan_jerk) */
+#define OTG_PROF3_LEN 49
 typedef struct {
 	otg_profile prof[OTG_MAX_DOF];
 	double duration;
+	int third_order;
+	double prof3[OTG_MAX_DOF][OTG_PROF3_LEN];
 } otg_traj;
 
 /* OutputParameter subset (output_parameter.hpp:27-52) */
@@ -100,6 +110,8 @@ void otg_joints_init(otg_joints* o, int dim, const double* initial_position, dou
 void otg_joints_reinitialize(otg_joints* o, const double* initial_position);
 void otg_joints_set_limits(otg_joints* o, const double* max_velocity, const double* max_acceleration);
 void otg_joints_disable_jerk_limits(otg_joints* o);
+void otg_joints_set_max_jerk(otg_joints* o, const double* max_jerk); /* OTG_joints::setMaxJerk (OTG_joints.cpp:73-86) */
+int otg_jerk_planner_available(void);
 void otg_joints_set_goal(otg_joints* o, const double* goal_position, const double* goal_velocity);
 void otg_joints_update(otg_joints* o);
 
@@ -119,6 +131,8 @@ void otg_cartesian_reinitialize_linear(otg_cartesian* o, const double* position)
 void otg_cartesian_reinitialize_angular(otg_cartesian* o, const double* orientation);
 void otg_cartesian_set_limits(otg_cartesian* o, double max_lin_vel, double max_lin_acc,
 							  double max_ang_vel, double max_ang_acc);
+/* setMaxJerk / disableJerkLimits (OTG_6dof_cartesian.cpp:126-136, .h:167-169); <= 0 or inf: disabled */
+void otg_cartesian_set_max_jerk(otg_cartesian* o, double max_lin_jerk, double max_ang_jerk);
 void otg_cartesian_set_goal_position(otg_cartesian* o, const double* pos, const double* lin_vel);
 void otg_cartesian_set_goal_orientation(otg_cartesian* o, const double* rot, const double* ang_vel);
 void otg_cartesian_update(otg_cartesian* o);

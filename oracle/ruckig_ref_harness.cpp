@@ -182,4 +182,42 @@ int rref_calculate_and_sample_jerk(int dofs, int sync, const double* cp, const d
 	}
 	return (int)r;
 }
+
+/* The reference's jerk-limited planner as the ORACLE's planner: Ruckig::calculate for one input, the resulting
+ * trajectory handed back as plain numbers, 49 per DoF: brake.duration, brake.t[2], j[2], a[2], v[2], p[2], then
+ * t_sum[7], j[7], a[8], v[8], p[8] of the profile (profile.hpp:46-50) — what Trajectory::at_time needs. oracle/
+ * otg_oracle.c samples them itself (its wrappers and Ruckig::update are restated there; the third-order planner is
+ * not: for it the oracle IS the reference's code). Returns the Result. */
+int rref_plan_jerk(int dofs, int sync, const double* cp, const double* cv, const double* ca, const double* tp, const double* tv,
+				   const double* vmax, const double* amax, const double* jmax, double* duration, double* prof) {
+	const size_t n = (size_t)dofs;
+	Ruckig<DynamicDOFs> otg(n, 0.001);
+	InputParameter<DynamicDOFs> in(n);
+	Trajectory<DynamicDOFs> traj(n);
+	in.synchronization = (Synchronization)sync;
+	for (size_t i = 0; i < n; ++i) {
+		in.current_position[i] = cp[i];
+		in.current_velocity[i] = cv[i];
+		in.current_acceleration[i] = ca[i];
+		in.target_position[i] = tp[i];
+		in.target_velocity[i] = tv[i];
+		in.max_velocity[i] = vmax[i];
+		in.max_acceleration[i] = amax[i];
+		in.max_jerk[i] = jmax[i];
+	}
+	const Result r = otg.calculate(in, traj);
+	*duration = 0.0;
+	if (r != Result::Working) return (int)r;
+	*duration = traj.get_duration();
+	const auto profiles = traj.get_profiles();
+	for (size_t d = 0; d < n; ++d) {
+		const Profile& p = profiles[0][d];
+		double* o = prof + 49 * d;
+		o[0] = p.brake.duration;
+		for (int k = 0; k < 2; k++) o[1 + k] = p.brake.t[k], o[3 + k] = p.brake.j[k], o[5 + k] = p.brake.a[k], o[7 + k] = p.brake.v[k], o[9 + k] = p.brake.p[k];
+		for (int k = 0; k < 7; k++) o[11 + k] = p.t_sum[k], o[18 + k] = p.j[k];
+		for (int k = 0; k < 8; k++) o[25 + k] = p.a[k], o[33 + k] = p.v[k], o[41 + k] = p.p[k];
+	}
+	return (int)r;
+}
 }

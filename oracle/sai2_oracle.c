@@ -422,6 +422,7 @@ int oracle_default_joint_task(sai2b_task_config* c, const char* name, int task_d
 	c->use_velocity_saturation = 0;
 	c->use_internal_otg = 1; /* JointTask.h:38-39 */
 	c->internal_otg_jerk_limited = 0;
+	for (int i = 0; i < SAI2B_MAX_DOF; i++) c->otg_max_jerk[i] = 10.0 * M_PI; /* JointTask.h:42 */
 	c->robot_dof = N7;
 	return 0;
 }
@@ -515,6 +516,7 @@ int oracle_default_motion_force_task(sai2b_task_config* c, const char* name, int
 	sh_defaults(c);
 	c->use_internal_otg = 1; /* MotionForceTask.h:67-72 */
 	c->internal_otg_jerk_limited = 0;
+	c->otg_max_linear_jerk = 10.0, c->otg_max_angular_jerk = 10.0 * M_PI; /* MotionForceTask.h:73-74 */
 	c->otg_max_linear_velocity = 0.3;
 	c->otg_max_linear_acceleration = 2.0;
 	c->otg_max_angular_velocity = M_PI / 3;
@@ -799,17 +801,22 @@ static void jt_reinit(const sai2b_task_config* t, const robot_t* r, jt_t* s, otg
 	}
 	otg_joints_reinitialize(o, s->cur_pos);
 }
-/* JointTask::enableInternalOtgAccelerationLimited (JointTask.cpp:360-381) */
-static void jt_otg_enable(const sai2b_task_config* t, const jt_t* s, otg_joints* o, int was_enabled) {
-	if (!was_enabled) otg_joints_reinitialize(o, s->cur_pos);
+/* JointTask::enableInternalOtgAccelerationLimited / enableInternalOtgJerkLimited (JointTask.cpp:360-406): the
+ * generator restarts at the task's current position when it was off or when the kind of limitation changes */
+static void jt_otg_enable(const sai2b_task_config* t, const jt_t* s, otg_joints* o, int was_enabled, int was_jerk) {
+	const int jerk = t->internal_otg_jerk_limited != 0;
+	if (!was_enabled || was_jerk != jerk) otg_joints_reinitialize(o, s->cur_pos);
 	otg_joints_set_limits(o, t->otg_max_velocity, t->otg_max_acceleration);
-	otg_joints_disable_jerk_limits(o);
+	if (jerk)
+		otg_joints_set_max_jerk(o, t->otg_max_jerk);
+	else
+		otg_joints_disable_jerk_limits(o);
 }
 /* JointTask::initialSetup, OTG part + reInitializeTask (JointTask.cpp:50,70-89) */
 static void jt_construct(const sai2b_task_config* t, const robot_t* r, jt_t* s, otg_joints* o) {
 	mm(t->task_dof, N7, 1, t->joint_selection, r->q, s->cur_pos);
 	otg_joints_init(o, t->task_dof, s->cur_pos, t->loop_timestep);
-	if (t->use_internal_otg) jt_otg_enable(t, s, o, 0);
+	if (t->use_internal_otg) jt_otg_enable(t, s, o, 0, 0);
 	jt_reinit(t, r, s, o);
 }
 static void jt_update(const sai2b_task_config* t, const robot_t* r, jt_t* s, const double* N_prec) {
@@ -919,17 +926,19 @@ static void mft_reinit(const oracle_ctx* c, const sai2b_task_config* t, const ro
 	memcpy(s->des_rot, s->g_rot, sizeof(s->des_rot));
 	otg_cartesian_reinitialize(o, s->cur_pos, s->cur_rot);
 }
-/* MotionForceTask::enableInternalOtgAccelerationLimited (MotionForceTask.cpp:511-523) */
-static void mft_otg_enable(const sai2b_task_config* t, const mft_t* s, otg_cartesian* o, int was_enabled) {
-	if (!was_enabled) otg_cartesian_reinitialize(o, s->cur_pos, s->cur_rot);
+/* MotionForceTask::enableInternalOtgAccelerationLimited / enableInternalOtgJerkLimited (MotionForceTask.cpp:511-538) */
+static void mft_otg_enable(const sai2b_task_config* t, const mft_t* s, otg_cartesian* o, int was_enabled, int was_jerk) {
+	const int jerk = t->internal_otg_jerk_limited != 0;
+	if (!was_enabled || was_jerk != jerk) otg_cartesian_reinitialize(o, s->cur_pos, s->cur_rot);
 	otg_cartesian_set_limits(o, t->otg_max_linear_velocity, t->otg_max_linear_acceleration,
 							 t->otg_max_angular_velocity, t->otg_max_angular_acceleration);
+	otg_cartesian_set_max_jerk(o, jerk ? t->otg_max_linear_jerk : INFINITY, jerk ? t->otg_max_angular_jerk : INFINITY);
 }
 /* MotionForceTask::initialSetup, OTG part + reInitializeTask (MotionForceTask.cpp:100-103,170-201) */
 static void mft_construct(const oracle_ctx* c, const sai2b_task_config* t, const robot_t* r, mft_t* s, otg_cartesian* o) {
 	det_pose(c, t, r->q, s->cur_pos, s->cur_rot);
 	otg_cartesian_init(o, s->cur_pos, s->cur_rot, t->loop_timestep);
-	if (t->use_internal_otg) mft_otg_enable(t, s, o, 0);
+	if (t->use_internal_otg) mft_otg_enable(t, s, o, 0, 0);
 	mft_reinit(c, t, r, s, o);
 }
 static void popc_init(mft_t* s) { /* POPCExplicitForceControl.cpp:10-22 */
@@ -1515,26 +1524,30 @@ int oracle_update_task_config(oracle_ctx* c, int task, const sai2b_task_config* 
 		return fail("update_task_config: bad arguments");
 	if (c->mft[task] && (cfg->passivity_enabled != 0) != (c->cfg[task].passivity_enabled != 0))
 		for (int b = 0; b < c->B; b++) popc_init(&c->mft[task][b]); /* enable()/disable() */
-	if (cfg->internal_otg_jerk_limited) return fail("update_task_config: jerk-limited OTG is not restated");
-	/* enableInternalOtgAccelerationLimited() is applied when the OTG fields change */
+	if (cfg->internal_otg_jerk_limited && cfg->use_internal_otg && !otg_jerk_planner_available())
+		return fail("update_task_config: the jerk-limited OTG needs oracle/_ref/libruckig_ref.so (make -C oracle ref)");
+	/* enableInternalOtgAccelerationLimited() / ...JerkLimited() is applied when the OTG fields change */
 	const sai2b_task_config* old = &c->cfg[task];
-	int otg_changed = (cfg->use_internal_otg != 0) != (old->use_internal_otg != 0);
+	const int jerk = cfg->internal_otg_jerk_limited != 0, was_jerk = old->internal_otg_jerk_limited != 0;
+	int otg_changed = (cfg->use_internal_otg != 0) != (old->use_internal_otg != 0) || jerk != was_jerk;
 	if (c->jt[task]) {
 		for (int i = 0; i < cfg->task_dof; i++)
 			otg_changed |= cfg->otg_max_velocity[i] != old->otg_max_velocity[i] ||
-						   cfg->otg_max_acceleration[i] != old->otg_max_acceleration[i];
+						   cfg->otg_max_acceleration[i] != old->otg_max_acceleration[i] ||
+						   (jerk && cfg->otg_max_jerk[i] != old->otg_max_jerk[i]);
 	} else {
 		otg_changed |= cfg->otg_max_linear_velocity != old->otg_max_linear_velocity ||
 					   cfg->otg_max_linear_acceleration != old->otg_max_linear_acceleration ||
 					   cfg->otg_max_angular_velocity != old->otg_max_angular_velocity ||
-					   cfg->otg_max_angular_acceleration != old->otg_max_angular_acceleration;
+					   cfg->otg_max_angular_acceleration != old->otg_max_angular_acceleration ||
+					   (jerk && (cfg->otg_max_linear_jerk != old->otg_max_linear_jerk || cfg->otg_max_angular_jerk != old->otg_max_angular_jerk));
 	}
 	if (cfg->use_internal_otg && otg_changed)
 		for (int b = 0; b < c->B; b++) {
 			if (c->jt[task])
-				jt_otg_enable(cfg, &c->jt[task][b], &c->jotg[task][b], old->use_internal_otg != 0);
+				jt_otg_enable(cfg, &c->jt[task][b], &c->jotg[task][b], old->use_internal_otg != 0, was_jerk);
 			else
-				mft_otg_enable(cfg, &c->mft[task][b], &c->cotg[task][b], old->use_internal_otg != 0);
+				mft_otg_enable(cfg, &c->mft[task][b], &c->cotg[task][b], old->use_internal_otg != 0, was_jerk);
 		}
 	if (c->mft[task]) {
 		/* parametrizeForceMotionSpaces / parametrizeMomentRotMotionSpaces (MotionForceTask.cpp:830-890): a new

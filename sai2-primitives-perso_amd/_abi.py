@@ -122,6 +122,9 @@ class TaskConfig(C.Structure):
         ("otg_max_linear_acceleration", _d),
         ("otg_max_angular_velocity", _d),
         ("otg_max_angular_acceleration", _d),
+        ("otg_max_jerk", _d * MAX_DOF),
+        ("otg_max_linear_jerk", _d),
+        ("otg_max_angular_jerk", _d),
         ("unsafe_motion_gains", _i),
         ("robot_dof", _i),
     ]

@@ -519,7 +519,7 @@ class _InternalOtgView:
         return rc._ctrl.get_otg_status(idx)[0] != 0
 
     def getJerkLimitEnabled(self):
-        return False
+        return bool(self._t._cfg.use_internal_otg and self._t._cfg.internal_otg_jerk_limited)
 
     def getNextPosition(self):
         return self._t.getDesiredPosition()
@@ -752,7 +752,19 @@ class JointTask(_TaskBase):
         self._sync_cfg()
 
     def enableInternalOtgJerkLimited(self, max_velocity, max_acceleration, max_jerk):
-        raise ValueError("the jerk-limited internal OTG (enableInternalOtgJerkLimited) is not implemented in this build")
+        """JointTask.cpp:383-406 (scalars or per-task-dof vectors): ruckig's jerk-limited interface"""
+        k0 = self._cfg.task_dof
+        v, a, j = (np.broadcast_to(np.asarray(x, dtype=float), (k0,)) for x in (max_velocity, max_acceleration, max_jerk))
+        if v.min() <= 0:
+            raise ValueError("max velocity cannot be 0 or negative in any directions in OTG_joints::setMaxVelocity\n")
+        if a.min() <= 0:
+            raise ValueError("max acceleration cannot be 0 or negative in any directions in OTG_joints::setMaxAcceleration\n")
+        if j.min() <= 0:
+            raise ValueError("max jerk cannot be 0 or negative in any directions in OTG_joints::setMaxJerk\n")
+        for i in range(k0):
+            self._cfg.otg_max_velocity[i], self._cfg.otg_max_acceleration[i], self._cfg.otg_max_jerk[i] = v[i], a[i], j[i]
+        self._cfg.use_internal_otg, self._cfg.internal_otg_jerk_limited = 1, 1
+        self._sync_cfg()
 
     def disableInternalOtg(self):
         """JointTask.h:320: desired state = goal state"""
@@ -933,8 +945,21 @@ class MotionForceTask(_TaskBase):
         c.use_internal_otg, c.internal_otg_jerk_limited = 1, 0
         self._sync_cfg()
 
-    def enableInternalOtgJerkLimited(self, *args):
-        raise ValueError("the jerk-limited internal OTG (enableInternalOtgJerkLimited) is not implemented in this build")
+    def enableInternalOtgJerkLimited(self, max_linear_velocity, max_linear_acceleration, max_linear_jerk, max_angular_velocity,
+                                     max_angular_acceleration, max_angular_jerk):
+        """MotionForceTask.cpp:525-538: ruckig's jerk-limited interface"""
+        c = self._cfg
+        if min(max_linear_velocity, max_angular_velocity) <= 0:
+            raise ValueError("max velocity set to 0 or negative value in some directions in OTG_6dof_cartesian::setMaxLinearVelocity\n")
+        if min(max_linear_acceleration, max_angular_acceleration) <= 0:
+            raise ValueError("max acceleration set to 0 or negative value in some directions in OTG_6dof_cartesian::setMaxLinearAcceleration\n")
+        if min(max_linear_jerk, max_angular_jerk) <= 0:
+            raise ValueError("max jerk set to 0 or negative value in some directions in OTG_6dof_cartesian::setMaxJerk\n")
+        c.otg_max_linear_velocity, c.otg_max_linear_acceleration = float(max_linear_velocity), float(max_linear_acceleration)
+        c.otg_max_angular_velocity, c.otg_max_angular_acceleration = float(max_angular_velocity), float(max_angular_acceleration)
+        c.otg_max_linear_jerk, c.otg_max_angular_jerk = float(max_linear_jerk), float(max_angular_jerk)
+        c.use_internal_otg, c.internal_otg_jerk_limited = 1, 1
+        self._sync_cfg()
 
     def disableInternalOtg(self):
         """MotionForceTask.h:423: desired state = goal state"""

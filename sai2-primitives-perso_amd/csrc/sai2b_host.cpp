@@ -284,6 +284,7 @@ extern "C" int sai2b_default_joint_task(sai2b_task_config* c, const char* name, 
 	}
 	c->use_internal_otg = 1;  // JointTask.h:38-39: on, acceleration-limited
 	c->internal_otg_jerk_limited = 0;
+	for (int i = 0; i < SAI2B_MAX_DOF; i++) c->otg_max_jerk[i] = 10.0 * M_PI;  // JointTask.h:42
 	c->robot_dof = N;
 	return SAI2B_OK;
 }
@@ -337,6 +338,7 @@ extern "C" int sai2b_default_motion_force_task(sai2b_task_config* c, const char*
 	singularity_defaults(c);
 	c->use_internal_otg = 1;  // MotionForceTask.h:67-72: on, acceleration-limited
 	c->internal_otg_jerk_limited = 0;
+	c->otg_max_linear_jerk = 10.0, c->otg_max_angular_jerk = 10.0 * M_PI;  // MotionForceTask.h:73-74
 	c->otg_max_linear_velocity = 0.3, c->otg_max_linear_acceleration = 2.0;
 	c->otg_max_angular_velocity = M_PI / 3, c->otg_max_angular_acceleration = 2.0 * M_PI;
 	c->robot_dof = N;
@@ -410,10 +412,18 @@ extern "C" int sai2b_validate_tasks(const sai2b_task_config* tasks, int n_tasks,
 			err = "singular_vector_sign must be one of enum sai2b_singular_vector_sign";
 		if (err.empty() && (t.dynamic_decoupling_type < SAI2B_FULL_DYNAMIC_DECOUPLING || t.dynamic_decoupling_type > SAI2B_IMPEDANCE))
 			err = "dynamic_decoupling_type must be FULL_DYNAMIC_DECOUPLING, BOUNDED_INERTIA_ESTIMATES or IMPEDANCE";
+		if (err.empty() && t.use_internal_otg && t.internal_otg_jerk_limited) {	 // setMaxJerk (OTG_joints.cpp:73-86, OTG_6dof_cartesian.cpp:126-136)
+			if (t.type == SAI2B_JOINT_TASK) {
+				for (int k = 0; err.empty() && k < t.task_dof; k++)
+					if (!(t.otg_max_jerk[k] > 0) || std::isinf(t.otg_max_jerk[k]))
+						err = "max jerk cannot be 0 or negative in any directions in OTG_joints::setMaxJerk\n";
+			} else if (!(t.otg_max_linear_jerk > 0) || !(t.otg_max_angular_jerk > 0) || std::isinf(t.otg_max_linear_jerk) ||
+					   std::isinf(t.otg_max_angular_jerk)) {
+				err = "max jerk set to 0 or negative value in some directions in OTG_6dof_cartesian::setMaxJerk\n";
+			}
+		}
 		if (err.empty() && t.use_internal_otg) {
-			if (t.internal_otg_jerk_limited)
-				err = "the jerk-limited internal OTG (enableInternalOtgJerkLimited) is not implemented in this build";
-			else if (t.type == SAI2B_JOINT_TASK) {
+			if (t.type == SAI2B_JOINT_TASK) {
 				for (int k = 0; err.empty() && k < t.task_dof; k++) {
 					if (!(t.otg_max_velocity[k] > 0))
 						err = "max velocity cannot be 0 or negative in any directions in OTG_joints::setMaxVelocity\n";
@@ -564,14 +574,17 @@ static void fill_dev_task(const sai2b_task_config& c, DevTask& d) {
 	d.sv_sign = c.singular_vector_sign;
 	// internal OTG: one generator DoF per task dof (JT) or 3 linear + 3 angular (MFT)
 	d.otg_on = c.use_internal_otg ? 1 : 0;
+	d.otg_jerk = (c.use_internal_otg && c.internal_otg_jerk_limited) ? 1 : 0;
 	d.otg_n = c.type == SAI2B_JOINT_TASK ? c.task_dof : 6;
 	for (int i = 0; i < sai2b::OTG_MD; i++) {
 		if (c.type == SAI2B_JOINT_TASK) {
 			d.otg_vmax[i] = i < c.task_dof ? c.otg_max_velocity[i] : 0.0;
 			d.otg_amax[i] = i < c.task_dof ? c.otg_max_acceleration[i] : 0.0;
+			d.otg_jmax[i] = i < c.task_dof ? c.otg_max_jerk[i] : 0.0;
 		} else {
 			d.otg_vmax[i] = i < 3 ? c.otg_max_linear_velocity : i < 6 ? c.otg_max_angular_velocity : 0.0;
 			d.otg_amax[i] = i < 3 ? c.otg_max_linear_acceleration : i < 6 ? c.otg_max_angular_acceleration : 0.0;
+			d.otg_jmax[i] = i < 3 ? c.otg_max_linear_jerk : i < 6 ? c.otg_max_angular_jerk : 0.0;
 		}
 	}
 }
@@ -693,6 +706,8 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 		const size_t goal_rows = tasks[t].type == SAI2B_MOTION_FORCE_TASK ? (size_t)sai2b::MFT_GOAL_ROWS : 3 * (size_t)d.k0;
 		if ((rc = dev_alloc(ctx, &d.otg_desired, goal_rows * Bs))) return rc;
 		if ((rc = dev_alloc(ctx, &d.otg_state, (size_t)sai2b::OTG_ROWS * Bs))) return rc;
+		d.otg3_traj = nullptr;
+		if (d.otg_jerk && (rc = dev_alloc(ctx, &d.otg3_traj, (size_t)sai2b::OTG_MD * sai2b::OTG3_STRIDE * Bs))) return rc;
 		d.otg_epoch = 0.0;
 		d.otg_out_is_desired = (tasks[t].type == SAI2B_JOINT_TASK && d.k0 == N && N == sai2b::OTG_MD) ? 1 : 0;  // same row stride
 		d.law_goals = d.otg_on ? (d.otg_out_is_desired ? d.otg_state + (size_t)sai2b::OTG_OUT * Bs : d.otg_desired) : d.goals;
@@ -807,6 +822,11 @@ extern "C" int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_ta
 	d.dbg_tau = keep.dbg_tau, d.dbg_N = keep.dbg_N, d.dbg_sigma = keep.dbg_sigma, d.dbg_J = keep.dbg_J, d.dbg_pose = keep.dbg_pose;
 	d.dbg_F = keep.dbg_F;
 	d.otg_desired = keep.otg_desired, d.otg_state = keep.otg_state, d.otg_epoch = keep.otg_epoch;
+	d.otg3_traj = keep.otg3_traj;
+	if (d.otg_jerk && !d.otg3_traj) {
+		int rc5 = dev_alloc(ctx, &d.otg3_traj, (size_t)sai2b::OTG_MD * sai2b::OTG3_STRIDE * (size_t)ctx->B);
+		if (rc5) return rc5;
+	}
 	d.otg_out_is_desired = keep.otg_out_is_desired, d.otg_gated = keep.otg_gated;
 	d.law_goals = d.otg_on ? (d.otg_out_is_desired ? d.otg_state + (size_t)sai2b::OTG_OUT * ctx->B : d.otg_desired) : d.goals;
 	ctx->params_dirty = true;
@@ -815,15 +835,23 @@ extern "C" int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_ta
 	// applied when the OTG fields change: new limits make every moving robot re-plan
 	// (InputParameter::operator!=, input_parameter.hpp:362-394); a generator that was off is
 	// re-initialised at the current state first
+	// enableInternalOtgJerkLimited (JointTask.cpp:383-406, MotionForceTask.cpp:525-538) likewise; a generator that is on and
+	// changes its kind of limitation (getJerkLimitEnabled() differs) restarts at the task's current pose too, and
+	// setMaxJerk, unlike disableJerkLimits, does not touch the input acceleration
+	const bool mode_changed = keep.otg_on && d.otg_jerk != keep.otg_jerk;
 	const bool limits_changed = std::memcmp(d.otg_vmax, keep.otg_vmax, sizeof(d.otg_vmax)) != 0 ||
-								std::memcmp(d.otg_amax, keep.otg_amax, sizeof(d.otg_amax)) != 0;
-	if (d.otg_on && (limits_changed || !keep.otg_on)) {
-		if (limits_changed) d.otg_epoch += 1.0;
+								std::memcmp(d.otg_amax, keep.otg_amax, sizeof(d.otg_amax)) != 0 ||
+								(d.otg_jerk && std::memcmp(d.otg_jmax, keep.otg_jmax, sizeof(d.otg_jmax)) != 0);
+	if (d.otg_on && (limits_changed || mode_changed || !keep.otg_on)) {
+		if (limits_changed || mode_changed) d.otg_epoch += 1.0;
+		const int reinit_mode = (!keep.otg_on || mode_changed) ? 1 : (d.otg_jerk ? -1 : 2);
 		int rc3 = upload_params(ctx);
 		if (rc3) return rc3;
-		if (sai2b_launch_otg_reinit(ctx->d_params, ctx->B, task, keep.otg_on ? 2 : 1, ctx->q_is_pose ? ctx->q : ctx->q_pose, ctx->stream))
-			return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG enable launch failed");
-		ctx->launches++;
+		if (reinit_mode >= 0) {
+			if (sai2b_launch_otg_reinit(ctx->d_params, ctx->B, task, reinit_mode, ctx->q_is_pose ? ctx->q : ctx->q_pose, ctx->stream))
+				return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG enable launch failed");
+			ctx->launches++;
+		}
 	}
 	if (reparam) {
 		int rc4 = upload_params(ctx);
@@ -1010,6 +1038,13 @@ static int generic_lanes(const sai2b_ctx* ctx, bool whole_batch) {
 	return (whole_batch && ctx->B >= 16384) ? 8 : 16;
 }
 
+// tasks whose generator is jerk-limited: their planner work lists take a launch of their own (sai2b_otg.hip)
+static int jerk_mask(const sai2b_ctx* ctx) {
+	int m = 0;
+	for (int t = 0; t < ctx->T; t++)
+		if (ctx->h_params.task[t].otg_on && ctx->h_params.task[t].otg_jerk) m |= 1 << t;
+	return m;
+}
 static bool any_otg(const sai2b_ctx* ctx) {
 	for (int t = 0; t < ctx->T; t++)
 		if (ctx->h_params.task[t].otg_on) return true;
@@ -1073,7 +1108,7 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 		// (a gated task keeps reading its goals: a robot skipped while they changed must see them later)
 		const int clean_mask = ctx->goals_exposed ? 0 : (int)(~ctx->goals_dirty & ~gated & ((1u << SAI2B_MAX_TASKS) - 1u));
 		ctx->goals_dirty = 0;
-		if (sai2b_launch_otg(ctx->d_params, ctx->B, ctx->otg_counts, ctx->otg_list, ctx->otg_parity, clean_mask, ~0, ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG launch failed");
+		if (sai2b_launch_otg(ctx->d_params, ctx->B, ctx->otg_counts, ctx->otg_list, ctx->otg_parity, clean_mask, ~0, jerk_mask(ctx), ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG launch failed");
 		ctx->otg_parity ^= 1;
 		ctx->launches += 2;
 	}
@@ -1223,7 +1258,7 @@ extern "C" int sai2b_task_compute_torques(sai2b_ctx* ctx, int task, const double
 		}
 		const int clean = ctx->goals_exposed ? 0 : (int)(~ctx->goals_dirty & ~gated & (1u << task));
 		ctx->goals_dirty &= ~(1u << task);
-		if (sai2b_launch_otg(ctx->d_params, ctx->B, ctx->otg_counts, ctx->otg_list, ctx->otg_parity, clean, 1 << task, ctx->stream))
+		if (sai2b_launch_otg(ctx->d_params, ctx->B, ctx->otg_counts, ctx->otg_list, ctx->otg_parity, clean, 1 << task, jerk_mask(ctx), ctx->stream))
 			return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG launch failed");
 		ctx->otg_parity ^= 1;
 		ctx->launches += 2;

@@ -34,7 +34,7 @@ extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, i
 // internal OTG (sai2b_otg.hip): one update of every enabled generator; (re)initialisation (modes in the kernel's comment)
 // task_mask bit t: advance task t's generator (all enabled ones: ~0)
 extern "C" int sai2b_launch_otg(const sai2b::DevParams* d_params, int B, int* counts, int* list, int parity, int clean_mask,
-								int task_mask, hipStream_t stream);
+								int task_mask, int jerk_mask, hipStream_t stream);
 // q_pose: [7][B] joint positions the tasks' cached poses correspond to (read in mode 1 only)
 extern "C" int sai2b_launch_otg_reinit(const sai2b::DevParams* d_params, int B, int only_task, int mode, const double* q_pose,
 									   hipStream_t stream);

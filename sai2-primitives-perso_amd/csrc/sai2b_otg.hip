@@ -24,6 +24,7 @@
 #endif
 #include "sai2b_otg_core.hpp"
 #include "sai2b_otg_group.hpp"
+#include "sai2b_otg3_core.hpp"
 
 namespace sai2b {
 namespace {
@@ -242,10 +243,49 @@ DI void load_traj(const real* S, int n, bool cart, int B, int b, Gen& g) {
 
 // SAMPLE: Ruckig::update without a new calculation, then the wrapper's bookkeeping. `in_sync` on entry:
 // the input rows were not loaded (they equal the output, OTG_IN_SYNC).
+// Ruckig::update without a new calculation for a JERK-LIMITED generator (ruckig.hpp:205-215, trajectory.hpp:65-142): of
+// the stored third-order profile of each DoF only the phase the new time falls into is read (OTG3_* rows of otg3_traj)
+DI int sample_jerk(const DevTask& t, bool cart, int n, int B, int b, Gen& g) {
+	const real* S = t.otg_state;
+	const real* T3 = t.otg3_traj;
+	g.time = ld(S, OTG_TIME, B, b) + t.dt;
+	const double duration = ld(S, OTG_DURATION, B, b);
+	g.traj.duration = duration;
+	UNROLL for (int d = 0; d < MD; d++)
+		if (d < n) {
+			const int r = d * OTG3_STRIDE;
+			const double brake_duration = ld(T3, r + OTG3_BRAKE, B, b);
+			const double brake_t0 = brake_duration > 0 ? ld(T3, r + OTG3_BRAKE + 1, B, b) : 0.0;
+			double t_sum[7];
+			UNROLL for (int i = 0; i < 7; i++) t_sum[i] = ld(T3, r + OTG3_TSUM + i, B, b);
+			double t_in;
+			const int ph = otg3::phase_at(brake_duration, brake_t0, t_sum, duration, g.time, t_in);
+			double p0, v0, a0, j0;
+			if (ph >= 8) {	// brake pre-trajectory, phase ph - 8
+				const int k = ph - 8;
+				j0 = ld(T3, r + OTG3_BRAKE + 3 + k, B, b), a0 = ld(T3, r + OTG3_BRAKE + 5 + k, B, b);
+				v0 = ld(T3, r + OTG3_BRAKE + 7 + k, B, b), p0 = ld(T3, r + OTG3_BRAKE + 9 + k, B, b);
+			} else {
+				j0 = ph < 7 ? ld(T3, r + OTG3_J + ph, B, b) : 0.0;
+				a0 = ld(T3, r + OTG3_A + ph, B, b), v0 = ld(T3, r + OTG3_V + ph, B, b), p0 = ld(T3, r + OTG3_P + ph, B, b);
+			}
+			otg3::integrate(t_in, p0, v0, a0, j0, g.np[d], g.nv[d], g.na[d]);
+			g.ci.cp[d] = g.np[d], g.ci.cv[d] = g.nv[d], g.ci.ca[d] = g.na[d];
+		}
+	if (cart) {
+		UNROLL for (int i = 0; i < 9; i++) g.ref[i] = ld(S, OTG_CART + i, B, b);
+	}
+	return g.time > duration ? otg::FINISHED : otg::WORKING;
+}
+
 DI void sample_lane(const DevTask& t, bool cart, int n, int B, int b, Gen& g, bool in_sync) {
 	real* S = t.otg_state;
-	load_traj(S, n, cart, B, b, g);
-	g.result = otg::ruckig_sample(g, n, t.dt, otg::WORKING);
+	if (t.otg_jerk) {
+		g.result = sample_jerk(t, cart, n, B, b, g);
+	} else {
+		load_traj(S, n, cart, B, b, g);
+		g.result = otg::ruckig_sample(g, n, t.dt, otg::WORKING);
+	}
 	if (g.result == otg::WORKING) {
 		// both pass_to_input calls: input, Ruckig's stored input and output are one state again
 		if (!in_sync) st(S, OTG_IN_SYNC, B, b, 1.0);
@@ -390,6 +430,67 @@ DI void plan_group(const DevTask& t, bool cart, int n, int B, int b) {
 	}
 }
 
+// PLAN for a JERK-LIMITED generator, one lane per robot: setGoal...(goal); update(); with ruckig's third-order
+// interface (sai2b_otg3_core.hpp), DoF after DoF out of this lane's scratch memory. The wrapper state travels through
+// the same rows as for the acceleration-limited generator (load_head / load_body / store_state); only the stored
+// trajectory differs (otg3_traj).
+__device__ __noinline__ void plan_lane3(const DevTask& t, bool cart, int n, int B, int b) {
+	real* S = t.otg_state;
+	otg3::Gen g3;
+	{
+		Gen g;	// wrapper part of the state, through the common row layout
+		load_head(S, n, cart, B, b, g);
+		load_body(S, n, cart, B, b, g);
+		g3.in = g.in, g3.ci = g.ci;
+		UNROLL for (int d = 0; d < MD; d++) g3.np[d] = g.np[d], g3.nv[d] = g.nv[d], g3.na[d] = g.na[d], g3.jmax[d] = t.otg_jmax[d];
+		g3.time = g.time, g3.goal_reached = g.goal_reached, g3.result = g.result, g3.target_set = g.target_set;
+		g3.ci_init = g.ci_init, g3.ci_epoch = g.ci_epoch, g3.replanned = 0;
+		UNROLL for (int i = 0; i < 9; i++) g3.ref[i] = g.ref[i], g3.goal_R[i] = g.goal_R[i];
+		UNROLL for (int i = 0; i < 3; i++) g3.goal_w[i] = g.goal_w[i];
+		g3.traj.duration = g.traj.duration;
+	}
+	Goals G;
+	load_goals(t, cart, n, B, b, G);
+	if (cart) {
+		otg::cart_set_goal_position(g3, G.cp, G.cv);
+		otg::cart_set_goal_orientation(g3, G.cR, G.cw);
+		otg::cart_update(g3, t.dt, t.otg_vmax, t.otg_amax, t.otg_epoch);
+	} else {
+		otg::joints_set_goal(g3, n, G.jp, G.jv);
+		otg::joints_update(g3, n, t.dt, t.otg_vmax, t.otg_amax, t.otg_epoch);
+	}
+	if (g3.replanned) {
+		real* T3 = t.otg3_traj;
+		st(S, OTG_DURATION, B, b, g3.traj.duration);
+		for (int d = 0; d < n; d++) {
+			const otg3::Prof& p = g3.traj.prof[d];
+			const int r = d * OTG3_STRIDE;
+			st(T3, r + OTG3_BRAKE, B, b, p.brake.duration);
+			for (int k = 0; k < 2; k++) {
+				st(T3, r + OTG3_BRAKE + 1 + k, B, b, p.brake.t[k]), st(T3, r + OTG3_BRAKE + 3 + k, B, b, p.brake.j[k]);
+				st(T3, r + OTG3_BRAKE + 5 + k, B, b, p.brake.a[k]), st(T3, r + OTG3_BRAKE + 7 + k, B, b, p.brake.v[k]);
+				st(T3, r + OTG3_BRAKE + 9 + k, B, b, p.brake.p[k]);
+			}
+			for (int k = 0; k < 7; k++) st(T3, r + OTG3_TSUM + k, B, b, p.t_sum[k]), st(T3, r + OTG3_J + k, B, b, p.j[k]);
+			for (int k = 0; k < 8; k++) st(T3, r + OTG3_A + k, B, b, p.a[k]), st(T3, r + OTG3_V + k, B, b, p.v[k]), st(T3, r + OTG3_P + k, B, b, p.p[k]);
+		}
+	}
+	{
+		Gen g;
+		g.in = g3.in, g.ci = g3.ci;
+		UNROLL for (int d = 0; d < MD; d++) g.np[d] = g3.np[d], g.nv[d] = g3.nv[d], g.na[d] = g3.na[d];
+		g.time = g3.time, g.goal_reached = g3.goal_reached, g.result = g3.result, g.target_set = g3.target_set;
+		g.ci_init = g3.ci_init, g.ci_epoch = g3.ci_epoch;
+		UNROLL for (int i = 0; i < 9; i++) g.ref[i] = g3.ref[i], g.goal_R[i] = g3.goal_R[i];
+		UNROLL for (int i = 0; i < 3; i++) g.goal_w[i] = g3.goal_w[i];
+		store_state(S, n, cart, B, b, g);
+		if (cart)
+			store_desired_cart(t.otg_desired, B, b, g);
+		else if (!t.otg_out_is_desired)
+			store_desired_joints(t.otg_desired, n, B, b, g);
+	}
+}
+
 }  // namespace
 
 // Work list of the planner: per task a counter and the robot indices that need it this tick.
@@ -444,7 +545,7 @@ __global__ __launch_bounds__(64) void otg_plan_kernel(const DevParams* __restric
 #pragma unroll 1
 	for (int t = 0; t < P.n_tasks; t++) {
 		const DevTask& tk = P.task[t];
-		if (!tk.otg_on || !((task_mask >> t) & 1)) continue;
+		if (!tk.otg_on || tk.otg_jerk || !((task_mask >> t) & 1)) continue;  // (jerk-limited generators: otg3_plan_kernel)
 		const int cnt = ((const gint*)counts)[parity * SAI2B_MAX_TASKS + t];
 		// grid-stride over the list: the grid is sized for the machine, not for the worst-case list
 #pragma unroll 1
@@ -453,6 +554,26 @@ __global__ __launch_bounds__(64) void otg_plan_kernel(const DevParams* __restric
 			if (e >= cnt) continue;	 // uniform over the group
 			const int b = ((const gint*)list)[(size_t)t * B + e];
 			plan_group(tk, tk.type == SAI2B_MOTION_FORCE_TASK, tk.otg_n, B, b);
+		}
+	}
+}
+
+// The listed robots of the JERK-LIMITED generators, one lane each (plan_lane3). Launched behind otg_plan_kernel only
+// while some task is jerk-limited; a small grid striding over the lists bounds the scratch memory the third-order
+// planner needs per lane (~20 KB: seven DoFs of blocks, each with up to three stored profiles).
+__global__ __launch_bounds__(64) void otg3_plan_kernel(const DevParams* __restrict__ Pp, const int* __restrict__ counts,
+													   const int* __restrict__ list, int parity, int task_mask) {
+	const DevParams& P = *Pp;
+	const int B = P.B;
+#pragma unroll 1
+	for (int t = 0; t < P.n_tasks; t++) {
+		const DevTask& tk = P.task[t];
+		if (!tk.otg_on || !tk.otg_jerk || !((task_mask >> t) & 1)) continue;
+		const int cnt = ((const gint*)counts)[parity * SAI2B_MAX_TASKS + t];
+#pragma unroll 1
+		for (int e = blockIdx.x * 64 + threadIdx.x; e < cnt; e += gridDim.x * 64) {
+			const int b = ((const gint*)list)[(size_t)t * B + e];
+			plan_lane3(tk, tk.type == SAI2B_MOTION_FORCE_TASK, tk.otg_n, B, b);
 		}
 	}
 }
@@ -586,12 +707,18 @@ extern "C" int sai2b_launch_mft_reparam(const sai2b::DevParams* d_params, int B,
 // counts: [2][SAI2B_MAX_TASKS] ints, zero before the first call; list: [SAI2B_MAX_TASKS][B] ints;
 // parity alternates 0/1 between consecutive calls
 // clean_mask bit t: the host has not written task t's goals / OTG settings since the previous call
+// jerk_mask: tasks whose generator is jerk-limited (host knowledge: DevTask::otg_jerk) — their lists get a third launch
 extern "C" int sai2b_launch_otg(const sai2b::DevParams* d_params, int B, int* counts, int* list, int parity, int clean_mask,
-								int task_mask, hipStream_t stream) {
+								int task_mask, int jerk_mask, hipStream_t stream) {
 	const dim3 grid((B + 63) / 64), block(64);
 	hipLaunchKernelGGL(sai2b::otg_kernel, grid, block, 0, stream, d_params, counts, list, parity, clean_mask, task_mask);
 	const int plan_blocks = (B + 7) / 8 < 2048 ? (B + 7) / 8 : 2048;
 	hipLaunchKernelGGL(sai2b::otg_plan_kernel, dim3(plan_blocks), block, 0, stream, d_params, counts, (const int*)list, parity, task_mask);
+	if (jerk_mask & task_mask) {
+		const int blocks3 = (B + 63) / 64 < 256 ? (B + 63) / 64 : 256;
+		hipLaunchKernelGGL(sai2b::otg3_plan_kernel, dim3(blocks3), block, 0, stream, d_params, (const int*)counts, (const int*)list, parity,
+						   task_mask);
+	}
 	return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

@@ -77,6 +77,11 @@ struct DevTask {
 	int otg_gated;
 	double otg_vmax[OTG_MD], otg_amax[OTG_MD];
 	double otg_epoch;  // bumped when the limits change: every moving robot re-plans on its next tick
+	// jerk-limited generator (enableInternalOtgJerkLimited: JointTask.cpp:383-406, MotionForceTask.cpp:525-538): ruckig's
+	// third-order interface (sai2b_otg3_core.hpp); its stored trajectory lives in a buffer of its own
+	int otg_jerk;
+	double otg_jmax[OTG_MD];
+	double* otg3_traj;	// [OTG_MD * OTG3_STRIDE][B] or NULL while the task has never been jerk-limited
 	// device buffers of this task
 	double* goals;	// MFT [30][B]: pos3 rot9 v3 w3 a3 alpha3 f3 m3 ; JT [3*k0][B]: q dq ddq
 	double* law_goals;	 // what the control law tracks: `goals`, or `otg_desired` when the OTG is on
@@ -110,6 +115,9 @@ constexpr int OTG_TIME = 13 * OTG_MD, OTG_DURATION = OTG_TIME + 1, OTG_GOAL_REAC
 // the stored targets are equal; their rows (IN c*, CI c*, CI t*) are then not kept up to date
 constexpr int OTG_TRAJ = OTG_TIME + 8;  // per DoF: brake t a p v, p0 v0, t0 t1 t2 t6, a0 a2 a6
 constexpr int OTG_TRAJ_STRIDE = 13;
+// rows of otg3_traj per DoF (a third-order Profile as Trajectory::at_time needs it, profile.hpp:46-50, brake.hpp:27):
+// brake duration, t[2], j[2], a[2], v[2], p[2]; t_sum[7]; j[7]; a[8]; v[8]; p[8]
+constexpr int OTG3_BRAKE = 0, OTG3_TSUM = 11, OTG3_J = 18, OTG3_A = 25, OTG3_V = 33, OTG3_P = 41, OTG3_STRIDE = 49;
 constexpr int OTG_CART = OTG_TRAJ + OTG_MD * OTG_TRAJ_STRIDE;  // reference frame 9, goal orientation 9, goal angular velocity 3
 constexpr int OTG_IN_SYNC = OTG_CART + 21;
 constexpr int OTG_ACTIVE = OTG_CART + 22;  // gated JointTask only: 1 = the task has a non-empty range this tick

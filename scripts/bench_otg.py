@@ -2,7 +2,8 @@
 """Cost of the tasks' internal OTG on the C3 workload (65 536 Panda, MotionForceTask + JointTask),
 inputs resident in HBM: the fused tick with the generators off (BASELINE's definition), on but idle
 (goals reached), on with every robot mid-trajectory, and re-planning every tick (goals change each
-tick: the worst case)."""
+tick: the worst case). `python scripts/bench_otg.py 65536 jerk`: the same phases with both generators JERK-LIMITED
+(enableInternalOtgJerkLimited: ruckig's third-order interface, csrc/sai2b_otg3_core.hpp; one lane plans one robot)."""
 import os
 import sys
 import time
@@ -16,6 +17,7 @@ import sai2_primitives_perso_amd as pkg
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 ONLY_MOVING = len(sys.argv) > 2 and sys.argv[2] == "moving"  # profiling runs: just the all-moving phase
+JERK = len(sys.argv) > 2 and sys.argv[2] == "jerk"
 inp = pkg.workloads.make_inputs(3, B=B)
 
 
@@ -32,6 +34,8 @@ def timed(c, steps, before=None):
 
 def make(otg):
     cfg = [pkg.motion_force_task_config("m", internal_otg=otg), pkg.joint_task_config("j", internal_otg=otg)]
+    if otg and JERK:  # the reference's default jerk limits (MotionForceTask.h:73-74, JointTask.h:42)
+        cfg[0].internal_otg_jerk_limited = cfg[1].internal_otg_jerk_limited = 1
     c = pkg.Controller(pkg.panda_model(), cfg, B)
     c.set_state(inp["q"], inp["dq"])
     c.reinitialize()
@@ -43,7 +47,7 @@ if not ONLY_MOVING:
     pkg.workloads.load_inputs(c, inp)
     timed(c, 20)
     off = timed(c, 200)
-    print(f"OTG off            : {off * 1e6:7.1f} us/step  {B / off / 1e9:.2f} G ticks/s")
+    print(f"OTG off            : {off * 1e6:7.1f} us/step  {B / off / 1e9:.2f} G ticks/s" + ("   (generators below: jerk-limited)" if JERK else ""))
     c.close()
 
 c = make(True)

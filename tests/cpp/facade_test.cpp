@@ -458,10 +458,9 @@ static int example18(int B, const char* path, int ticks) {
 }
 
 // examples/02-joint_control_internal_otg/02-joint_control_internal_otg.cpp:118-179 call for call: one JointTask with
-// the acceleration-limited internal OTG, goal steps every "second", limits raised after "5 seconds"; the schedule of
-// cycles 1000 / 3000 of 4000, 5000 and 10000 is compressed to ticks/8, 3 ticks/8 of ticks/2, 5 ticks/8 and the last
-// period, where the example adds jerk limits — which this build refuses with the documented error (exit code 3 if
-// it did anything else). Prints, per period, the state read and the torques.
+// the acceleration-limited internal OTG, goal steps every "second", limits raised after "5 seconds", jerk limits added
+// after "10 seconds" and two more goal steps under them; with u = ticks/12 for the example's 1000 cycles: steps at u and
+// 3u of every 4u, new limits at 5u, jerk limits at 10u, end at 12u. Prints, per period, the state read and the torques.
 static int example02(int B, const char* path, int ticks) {
 	std::ifstream f(path, std::ios::binary);
 	Batch q0(7 * (size_t)B), dq0(7 * (size_t)B, 0.0);
@@ -476,7 +475,7 @@ static int example02(int B, const char* path, int ticks) {
 	joint_task->enableInternalOtgAccelerationLimited(M_PI / 3, M_PI);		 // :129
 	BatchedSimulation sim(*joint_task, 0.001, 1);
 	Batch N_prec(49 * (size_t)B, 0.0);
-	const int period = ticks / 2;
+	const int u = ticks / 12, period = 4 * u;
 	for (int cycle = 0; cycle < ticks; cycle++) {
 		const Batch q = sim.getJointPositions(), dq = sim.getJointVelocities();
 		std::fwrite(q.data(), sizeof(double), q.size(), stdout);
@@ -487,20 +486,13 @@ static int example02(int B, const char* path, int ticks) {
 		for (int i = 0; i < 7; i++)
 			for (int b = 0; b < B; b++) N_prec[(size_t)(8 * i) * B + b] = 1.0;	 // :146
 		joint_task->updateTaskModel(N_prec);									 // :147
-		if (cycle % period == period / 4)										 // :151-155
+		if (cycle % period == u)												 // :151-155
 			for (int b = 0; b < B; b++) goal_position[(size_t)1 * B + b] -= 0.2, goal_position[(size_t)2 * B + b] += 0.4, goal_position[(size_t)3 * B + b] -= 0.6;
-		if (cycle % period == 3 * period / 4)									 // :156-160
+		if (cycle % period == 3 * u)											 // :156-160
 			for (int b = 0; b < B; b++) goal_position[(size_t)1 * B + b] += 0.2, goal_position[(size_t)2 * B + b] -= 0.4, goal_position[(size_t)3 * B + b] += 0.6;
 		joint_task->setGoalPosition(goal_position);								 // :161
-		if (cycle == 5 * ticks / 8) joint_task->enableInternalOtgAccelerationLimited(M_PI, 3 * M_PI);  // :164-169
-		if (cycle == ticks - 1) {												 // :171-176
-			try {
-				joint_task->enableInternalOtgJerkLimited(M_PI, 3 * M_PI, 3 * M_PI);
-				return 3;
-			} catch (const std::invalid_argument& e) {
-				if (!std::strstr(e.what(), "jerk-limited")) return 3;
-			}
-		}
+		if (cycle == 5 * u) joint_task->enableInternalOtgAccelerationLimited(M_PI, 3 * M_PI);	 // :164-169
+		if (cycle == 10 * u) joint_task->enableInternalOtgJerkLimited(M_PI, 3 * M_PI, 3 * M_PI);  // :171-176
 		const Batch joint_task_torques = joint_task->computeTorques();	// :178
 		std::fwrite(joint_task_torques.data(), sizeof(double), joint_task_torques.size(), stdout);
 		sim.setJointTorques(joint_task_torques);
@@ -511,9 +503,9 @@ static int example02(int B, const char* path, int ticks) {
 
 // examples/03-cartesian_motion_control/03-cartesian_motion_control.cpp:109-183 call for call: one MotionForceTask with the
 // reference's default (acceleration-limited, Cartesian) internal OTG, goal steps of 0.1 m in z with a 45 degree turn
-// about z, the generator switched off later on; cycles 500 / 2000 of 3000, 6500 and 12500 are compressed to P/6 and
-// 2P/3 of P = ticks/2, 13 ticks/18 and the last period, where the example asks for jerk limits (refused by this
-// build; exit code 3 otherwise). Prints, per period, the state read and the torques.
+// about z, the generator switched off later on and switched back on with jerk limits; with u = ticks/30 for the example's
+// 500 cycles: steps at u and 4u of every 6u, generator off at 13u, jerk-limited at 25u (the cycle of a goal step, as in
+// the example: 12500 % 3000 == 500), one more step at 28u, end at 30u. Prints, per period, the state read and the torques.
 static int example03(int B, const char* path, int ticks) {
 	std::ifstream f(path, std::ios::binary);
 	Batch q0(7 * (size_t)B), dq0(7 * (size_t)B, 0.0);
@@ -530,7 +522,7 @@ static int example03(int B, const char* path, int ticks) {
 	Batch goal_position = motion_force_task->getCurrentPosition();
 	BatchedSimulation sim(*motion_force_task, 0.001, 1);
 	const double th = M_PI / 4.0, R[9] = {std::cos(th), std::sin(th), 0, -std::sin(th), std::cos(th), 0, 0, 0, 1};	// :156-158
-	const int period = ticks / 2;
+	const int u = ticks / 30, period = 6 * u;
 	auto turn = [&](bool transpose) {  // goal_orientation = R (or R^T) * goal_orientation
 		Batch out(goal_orientation.size());
 		for (int b = 0; b < B; b++)
@@ -550,24 +542,17 @@ static int example03(int B, const char* path, int ticks) {
 		robot->setDq(dq);
 		robot->updateModel();
 		motion_force_task->updateTaskModel();  // :151-152 N_prec = identity
-		if (cycle % period == 2 * period / 3) {	 // :159-162
+		if (cycle % period == 4 * u) {	// :159-162
 			for (int b = 0; b < B; b++) goal_position[(size_t)2 * B + b] += 0.1;
 			turn(false);
-		} else if (cycle % period == period / 6) {	// :164-167
+		} else if (cycle % period == u) {  // :164-167
 			for (int b = 0; b < B; b++) goal_position[(size_t)2 * B + b] -= 0.1;
 			turn(true);
 		}
 		motion_force_task->setGoalPosition(goal_position);		 // :168-169
 		motion_force_task->setGoalOrientation(goal_orientation);
-		if (cycle == 13 * ticks / 18) motion_force_task->disableInternalOtg();	// :172-174
-		if (cycle == ticks - 1) {												// :177-180
-			try {
-				motion_force_task->enableInternalOtgJerkLimited(0.3, 1.0, 3.0, M_PI / 3, M_PI, 3 * M_PI);
-				return 3;
-			} catch (const std::invalid_argument& e) {
-				if (!std::strstr(e.what(), "jerk-limited")) return 3;
-			}
-		}
+		if (cycle == 13 * u) motion_force_task->disableInternalOtg();														// :172-174
+		if (cycle == 25 * u) motion_force_task->enableInternalOtgJerkLimited(0.3, 1.0, 3.0, M_PI / 3, M_PI, 3 * M_PI);	// :177-180
 		const Batch motion_force_task_torques = motion_force_task->computeTorques();  // :182-183
 		std::fwrite(motion_force_task_torques.data(), sizeof(double), motion_force_task_torques.size(), stdout);
 		sim.setJointTorques(motion_force_task_torques);

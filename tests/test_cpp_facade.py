@@ -353,10 +353,13 @@ def test_cpp_example_11_planar_robot_controller(facade_bin, tmp_path):
 def test_cpp_example_02_joint_control_internal_otg(facade_bin, tmp_path):
     """tests/cpp/facade_test.cpp::example02 = examples/02-joint_control_internal_otg.cpp:118-179 call for call: a JointTask
     following goal steps along acceleration-limited trajectories, limits raised in mid-run (re-planning of moving
-    generators); the example's last phase (jerk limits) is refused by this build, which the program checks."""
+    generators), then jerk limits added (enableInternalOtgJerkLimited: ruckig's third-order interface) and two more goal
+    steps under them. On the oracle's side the jerk-limited planner is the reference's own ruckig (oracle/_ref)."""
     import oracle_lib as ol
 
-    B, ticks = 64, 640
+    if not ol.lib().otg_jerk_planner_available():
+        pytest.skip("oracle/_ref/libruckig_ref.so not built")
+    B, ticks = 64, 960
     inp = pkg.workloads.make_inputs(3, B=B, seed=202)
     path = tmp_path / "q.bin"
     inp["q"].astype(np.float64).tofile(path)
@@ -372,40 +375,53 @@ def test_cpp_example_02_joint_control_internal_otg(facade_bin, tmp_path):
     o.reinitialize()
     goal = inp["q"].copy()
     eye = np.repeat(np.eye(7).reshape(49, 1), B, axis=1)
-    period = ticks // 2
-    moved = 0.0
+    u = ticks // 12
+    period = 4 * u
+    moved = moved_jerk = 0.0
     for cycle in range(ticks):
         q, dq, tau_g = out[cycle]
         o.set_state(q, dq)
         o.task_update_model(0, eye)
-        if cycle % period == period // 4:
+        if cycle % period == u:
             goal[1] -= 0.2
             goal[2] += 0.4
             goal[3] -= 0.6
-        if cycle % period == 3 * period // 4:
+        if cycle % period == 3 * u:
             goal[1] += 0.2
             goal[2] -= 0.4
             goal[3] += 0.6
         o.set_jt_goals(0, goal)
-        if cycle == 5 * ticks // 8:
+        if cycle == 5 * u:
             for i in range(7):
                 cfg.otg_max_velocity[i], cfg.otg_max_acceleration[i] = np.pi, 3 * np.pi
             o.update_task_config(0, cfg)
+        if cycle == 10 * u:
+            cfg.internal_otg_jerk_limited = 1
+            for i in range(7):
+                cfg.otg_max_velocity[i], cfg.otg_max_acceleration[i], cfg.otg_max_jerk[i] = np.pi, 3 * np.pi, 3 * np.pi
+            o.update_task_config(0, cfg)
+            q_at_switch = q.copy()
         tau = o.task_compute_torques(0)
         assert _err(tau_g, tau) < 1e-9, (cycle, _err(tau_g, tau))
         moved = max(moved, np.abs(q - inp["q"]).max())
+        if cycle > 10 * u:
+            moved_jerk = max(moved_jerk, np.abs(q - q_at_switch).max())
     assert moved > 0.2  # the generators carried the joints towards the stepped goals
+    assert moved_jerk > 0.01  # ... also along the jerk-limited trajectories of the last phase
 
 
 @pytest.mark.gpu
 def test_cpp_example_03_cartesian_motion_control(facade_bin, tmp_path):
     """tests/cpp/facade_test.cpp::example03 = examples/03-cartesian_motion_control.cpp:109-183 call for call: a
     MotionForceTask following position + orientation goal steps along the Cartesian generator's trajectories
-    (new goals while still moving), the generator switched off in mid-run; the example's last phase (jerk limits) is
-    refused by this build, which the program checks."""
+    (new goals while still moving), the generator switched off in mid-run and back on with jerk limits
+    (enableInternalOtgJerkLimited) for the last goal steps. On the oracle's side the jerk-limited planner is the
+    reference's own ruckig (oracle/_ref)."""
     import oracle_lib as ol
 
-    B, ticks = 64, 900
+    if not ol.lib().otg_jerk_planner_available():
+        pytest.skip("oracle/_ref/libruckig_ref.so not built")
+    B, ticks = 64, 1200
     inp = pkg.workloads.make_inputs(3, B=B, seed=303)
     path = tmp_path / "q.bin"
     inp["q"].astype(np.float64).tofile(path)
@@ -423,21 +439,27 @@ def test_cpp_example_03_cartesian_motion_control(facade_bin, tmp_path):
     gp, gR = st["pos"].copy(), st["rot"].reshape(3, 3, B).copy()
     th = np.pi / 4
     R = np.array([[np.cos(th), np.sin(th), 0], [-np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
-    period = ticks // 2
+    u = ticks // 30
+    period = 6 * u
     worst_regular, moved = 0.0, 0.0
     for cycle in range(ticks):
         q, dq, tau_g = out[cycle]
         o.set_state(q, dq)
         o.task_update_model(0, None)
-        if cycle % period == 2 * period // 3:
+        if cycle % period == 4 * u:
             gp[2] += 0.1
             gR = np.einsum("ik,kjb->ijb", R, gR)
-        elif cycle % period == period // 6:
+        elif cycle % period == u:
             gp[2] -= 0.1
             gR = np.einsum("ki,kjb->ijb", R, gR)
         o.set_mft_goals(0, gp, np.ascontiguousarray(gR.reshape(9, B)), None, None, None, None)
-        if cycle == 13 * ticks // 18:
+        if cycle == 13 * u:
             cfg.use_internal_otg = 0
+            o.update_task_config(0, cfg)
+        if cycle == 25 * u:
+            cfg.use_internal_otg, cfg.internal_otg_jerk_limited = 1, 1
+            cfg.otg_max_linear_velocity, cfg.otg_max_linear_acceleration, cfg.otg_max_linear_jerk = 0.3, 1.0, 3.0
+            cfg.otg_max_angular_velocity, cfg.otg_max_angular_acceleration, cfg.otg_max_angular_jerk = np.pi / 3, np.pi, 3 * np.pi
             o.update_task_config(0, cfg)
         tau = o.task_compute_torques(0)
         _, _, ro = o.get_mft_singularity(0)

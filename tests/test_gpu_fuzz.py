@@ -126,6 +126,10 @@ def test_random_configuration_closed_loop(seed):
     assert np.abs(qg - qo).max() < 1e-9 and np.abs(dqg - dqo).max() < 1e-6, what
 
 
+# the run-time-event sweep draws the jerk-limited generator too (test_random_runtime_events_with_jerk_limited_generators)
+_JERK_EVENTS = False
+
+
 def _clone(cfg):
     return type(cfg).from_buffer_copy(cfg)
 
@@ -135,7 +139,7 @@ def _mutate(cfg, rng_state, all_cfgs):
     sai2b_update_task_config stands for); rng_state: a seed, so both sides draw the same numbers"""
     rng = np.random.default_rng(rng_state)
     c = _clone(cfg)
-    what = rng.integers(8)
+    what = rng.integers(9 if _JERK_EVENTS else 8)
     if what == 0:  # gains, per axis
         if c.type == pkg.MOTION_FORCE_TASK:
             for i in range(3):
@@ -157,6 +161,14 @@ def _mutate(cfg, rng_state, all_cfgs):
         else:
             for i in range(c.task_dof):
                 c.otg_max_velocity[i], c.otg_max_acceleration[i] = rng.uniform(0.3, 2), rng.uniform(1, 6)
+    elif what == 8:  # kind of limitation: enableInternalOtgJerkLimited / ...AccelerationLimited (generator re-initialised
+        # at the task's current pose when the kind changes), or new jerk limits on a jerk-limited generator
+        c.internal_otg_jerk_limited = int(rng.random() < 0.7)
+        if c.type == pkg.MOTION_FORCE_TASK:
+            c.otg_max_linear_jerk, c.otg_max_angular_jerk = rng.uniform(3, 30), rng.uniform(10, 60)
+        else:
+            for i in range(c.task_dof):
+                c.otg_max_jerk[i] = rng.uniform(10, 60)
     elif what == 3:  # velocity saturation
         c.use_velocity_saturation = int(rng.integers(2))
         if c.type == pkg.MOTION_FORCE_TASK:
@@ -316,6 +328,27 @@ def test_random_runtime_events_closed_loop(seed):
     """40 closed-loop periods with random run-time events applied to both sides in lock-step: new goals,
     task reconfiguration (_mutate), reinitialisation, integrator resets, new sensor readings, state jumps,
     gravity compensation switched"""
+    _events_run(seed, 0)
+
+
+@pytest.mark.skipif(not ol.lib().otg_jerk_planner_available(), reason="oracle/_ref/libruckig_ref.so not built")
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SAI2B_FUZZ_SEEDS", "16"))))
+def test_random_runtime_events_with_jerk_limited_generators(seed):
+    """the same sweep with one more event: a task's generator switched to jerk limitation (enableInternalOtgJerkLimited:
+    ruckig's third-order interface; on the oracle's side the reference's own ruckig plans), back, or given new jerk
+    limits while moving. The device planner's cbrt / acos / cos / sin are another library's than the reference's, so its
+    roots differ in the last bits: where ruckig's accept / reject thresholds or the choice among several valid profiles
+    sit on such a bit, a robot's generator may take another — valid — trajectory; such robots are set aside like in
+    round 1 and counted (at most 3 % of a batch)."""
+    global _JERK_EVENTS
+    _JERK_EVENTS = True
+    try:
+        _events_run(500000 + seed, max(1, int(0.03 * 200)))
+    finally:
+        _JERK_EVENTS = False
+
+
+def _events_run(seed, split_allowance):
     rng, name, tasks, otg, o, g = _event_run_setup(seed)
     B = o.B
     env = {"gravity": False}
@@ -346,7 +379,7 @@ def test_random_runtime_events_closed_loop(seed):
         # (since the bit-reproducible trigonometry and initialisation pose of round 2 — include/sai2b_detmath.h,
         # sai2b_detfk.h, shared by product and oracle — no robot takes another planner branch: the bound is 0)
         _SPLIT_STATS[seed] = (int(split.sum()), B)
-        assert split.sum() <= _SPLIT_BOUND(B), (seed, name, log[-6:], np.nonzero(split)[0])  # several such events in one run add up
+        assert split.sum() <= _SPLIT_BOUND(B) + split_allowance, (seed, name, log[-6:], np.nonzero(split)[0])  # several such events in one run add up
         e[split] = 0
         log[-1] = log[-1] + (float(f"{e.max():.1e}"),)
         ctx = (seed, name, otg, log[-6:])

@@ -194,12 +194,13 @@ def test_gpu_otg_enable_disable_and_limit_change():
         cfg.otg_max_linear_velocity, cfg.otg_max_angular_velocity = 0.1, 0.5
         c.update_task_config(0, cfg)
     assert step(60) < TOL
-    # jerk-limited generator: refused
+    # jerk-limited generator: its limits are checked like OTG_joints::setMaxJerk does (tests/test_gpu_otg3.py runs it)
     cfg = g.tasks[1]
     cfg.internal_otg_jerk_limited = 1
-    with pytest.raises(ValueError, match="jerk-limited"):
+    cfg.otg_max_jerk[2] = -1.0
+    with pytest.raises(ValueError, match="max jerk"):
         g.update_task_config(1, cfg)
-    cfg.internal_otg_jerk_limited = 0
+    cfg.internal_otg_jerk_limited, cfg.otg_max_jerk[2] = 0, 10 * np.pi
 
 
 def test_gpu_otg_reaches_goal_and_idles():
@@ -242,8 +243,8 @@ def test_gpu_facade_otg_on_by_default():
     v = jt.getDesiredVelocity()
     assert 0 < np.abs(v).max() <= 0.5 + 1e-12
     assert np.abs(jt.getDesiredPosition() - inp["jt1"]["q"]).max() > 1e-3  # still on its way
-    with pytest.raises(ValueError, match="jerk-limited"):
-        jt.enableInternalOtgJerkLimited(1.0, 1.0, 1.0)
+    with pytest.raises(ValueError, match="max jerk"):
+        jt.enableInternalOtgJerkLimited(1.0, 1.0, 0.0)
     with pytest.raises(ValueError, match="max velocity"):
         mft.enableInternalOtgAccelerationLimited(0.0, 1.0, 1.0, 1.0)
     jt.disableInternalOtg()

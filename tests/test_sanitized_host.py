@@ -148,8 +148,8 @@ def test_oracle_under_sanitizers(tmp_path):
     oracle's wrapper scenarios run through them"""
     tmp = str(tmp_path)
     lib = os.path.join(tmp, "libsai2_oracle_san.so")
-    subprocess.run(["gcc", "-std=gnu99", *SAN, "-fPIC", "-fopenmp", "-ffp-contract=off", "-shared", "-o", lib,
-                    os.path.join(ROOT, "oracle", "sai2_oracle.c"), os.path.join(ROOT, "oracle", "otg_oracle.c"), "-lm"], check=True)
+    subprocess.run(["gcc", "-std=gnu99", "-D_GNU_SOURCE", *SAN, "-fPIC", "-fopenmp", "-ffp-contract=off", "-shared", "-o", lib,
+                    os.path.join(ROOT, "oracle", "sai2_oracle.c"), os.path.join(ROOT, "oracle", "otg_oracle.c"), "-lm", "-ldl"], check=True)
     code = f"""
 import os, sys
 os.environ['SAI2B_ORACLE_LIB'] = {lib!r}
