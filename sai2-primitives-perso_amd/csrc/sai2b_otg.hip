@@ -278,11 +278,18 @@ DI int sample_jerk(const DevTask& t, bool cart, int n, int B, int b, Gen& g) {
 	return g.time > duration ? otg::FINISHED : otg::WORKING;
 }
 
-DI void sample_lane(const DevTask& t, bool cart, int n, int B, int b, Gen& g, bool in_sync) {
+// JERK: the instantiation of otg_kernel launched while some task's generator is jerk-limited; the other one compiles
+// exactly as it did before that mode existed (its registers and scratch are what the all-moving case is bound by)
+template <bool JERK> DI void sample_lane(const DevTask& t, bool cart, int n, int B, int b, Gen& g, bool in_sync) {
 	real* S = t.otg_state;
-	if (t.otg_jerk) {
-		g.result = sample_jerk(t, cart, n, B, b, g);
-	} else {
+	bool done = false;
+	if constexpr (JERK) {
+		if (t.otg_jerk) {
+			g.result = sample_jerk(t, cart, n, B, b, g);
+			done = true;
+		}
+	}
+	if (!done) {
 		load_traj(S, n, cart, B, b, g);
 		g.result = otg::ruckig_sample(g, n, t.dt, otg::WORKING);
 	}
@@ -501,6 +508,7 @@ __device__ __noinline__ void plan_lane3(const DevTask& t, bool cart, int n, int 
 // Every generator that is on, one robot per lane: idle and sampling robots are finished here; robots
 // that need the planner are appended to the task's work list (one atomic per wavefront, lanes of a
 // wavefront stay adjacent and ordered, so the plan kernel's accesses coalesce in runs).
+template <bool JERK>
 __global__ __launch_bounds__(64) void otg_kernel(const DevParams* __restrict__ Pp, int* __restrict__ counts,
 												 int* __restrict__ list, int parity, int clean_mask, int task_mask) {
 	const DevParams& P = *Pp;
@@ -519,7 +527,7 @@ __global__ __launch_bounds__(64) void otg_kernel(const DevParams* __restrict__ P
 			Goals G;
 			bool in_sync;
 			cls = classify(tk, cart, tk.otg_n, B, b, g, G, ((clean_mask >> t) & 1) != 0, in_sync);
-			if (cls == SAMPLE) sample_lane(tk, cart, tk.otg_n, B, b, g, in_sync);
+			if (cls == SAMPLE) sample_lane<JERK>(tk, cart, tk.otg_n, B, b, g, in_sync);
 		}
 		const unsigned long long mask = __ballot(cls == PLAN);
 		if (mask) {
@@ -711,7 +719,10 @@ extern "C" int sai2b_launch_mft_reparam(const sai2b::DevParams* d_params, int B,
 extern "C" int sai2b_launch_otg(const sai2b::DevParams* d_params, int B, int* counts, int* list, int parity, int clean_mask,
 								int task_mask, int jerk_mask, hipStream_t stream) {
 	const dim3 grid((B + 63) / 64), block(64);
-	hipLaunchKernelGGL(sai2b::otg_kernel, grid, block, 0, stream, d_params, counts, list, parity, clean_mask, task_mask);
+	if (jerk_mask & task_mask)
+		hipLaunchKernelGGL(sai2b::otg_kernel<true>, grid, block, 0, stream, d_params, counts, list, parity, clean_mask, task_mask);
+	else
+		hipLaunchKernelGGL(sai2b::otg_kernel<false>, grid, block, 0, stream, d_params, counts, list, parity, clean_mask, task_mask);
 	const int plan_blocks = (B + 7) / 8 < 2048 ? (B + 7) / 8 : 2048;
 	hipLaunchKernelGGL(sai2b::otg_plan_kernel, dim3(plan_blocks), block, 0, stream, d_params, counts, (const int*)list, parity, task_mask);
 	if (jerk_mask & task_mask) {
