@@ -39,6 +39,45 @@ __global__ __launch_bounds__(64) void tick_cert_kernel(const DevParams* __restri
 	UNROLL for (int i = 0; i < N; i++) st(P.tau, i, B, b, tau[i] + pend[i * 64]);  // RobotController.cpp:70-72
 }
 
+// The TemplateTask calls on one task (updateTaskModel(N_prec), computeTorques(), computeTorques(tau_prec), the nullspace
+// getters: TemplateTask.h:42-88) through the same whitened cascade (cert::tick<.., TASK = true>): what examples 01 / 04 /
+// 18 / 19 do by hand per period. Robots whose N_prec is not a whitened projector, whose level is not certified or that
+// carry singularity history go — nothing stored — to a work list for the generic task_kernel (sai2b_kernels.hip).
+// tk_count: one counter, zeroed by the host before the launch.
+template <int MCAP>
+__global__ __launch_bounds__(64) void task_cert_kernel(const DevParams* __restrict__ Pp, int task, const double* __restrict__ Nprec_in,
+													  const double* __restrict__ tau_prec, double* __restrict__ tau_out, double* __restrict__ N_out,
+													  double* __restrict__ Ntot_out, int do_torque, int* __restrict__ tk_count,
+													  int* __restrict__ tk_list) {
+	__shared__ real pend_lds[cert::LDS_SLOTS * 64];
+	__shared__ real q0_lds[(N * (N + 1) / 2) * 64];
+	const DevParams& P = *Pp;
+	const int B = P.B;
+	const int b = blockIdx.x * 64 + threadIdx.x;
+	if (b >= B) return;
+	real* pend = pend_lds + threadIdx.x;
+	cert::TaskArgs io;
+	io.task = task, io.Nprec = Nprec_in, io.tau_prec = tau_prec, io.N_out = N_out, io.Ntot_out = Ntot_out, io.q0 = q0_lds + threadIdx.x;
+	real tau[N];
+	const bool mine = cert::tick<MCAP, cert::DM, DevModel, true>(P, P.model, B, b, tau_prec != nullptr, pend, tau, &io);
+	const unsigned long long declined = __ballot(!mine);
+	if (declined) {
+		int base = 0;
+		if (threadIdx.x == 0) base = atomicAdd(tk_count, __popcll(declined));  // lane 0 is always in range
+		base = __shfl(base, 0);
+		if (!mine) {
+			((gint*)tk_list)[base + __popcll(declined & ((1ull << threadIdx.x) - 1ull))] = b;
+			return;
+		}
+	}
+	if (do_torque) {
+		cert::flush_task(P, task, B, b, pend);
+		if (tau_out) {
+			UNROLL for (int i = 0; i < N; i++) st(tau_out, i, B, b, tau[i] - (tau_prec ? ld(tau_prec, i, B, b) : 0.0));
+		}
+	}
+}
+
 // The range pass ahead of the trajectory generators (cert::range_tick): OTG_ACTIVE of the gated JointTasks for the
 // robots whose levels are all certified; the others go to a work list for the generic kernel's range pass, with
 // the same two alternating counters protocol as above.
@@ -84,6 +123,20 @@ extern "C" int sai2b_launch_range_cert(const sai2b::DevParams* d_params, int B, 
 		hipLaunchKernelGGL(sai2b::range_cert_kernel<3>, grid, block, 0, stream, d_params, rg_counts, rg_list, parity);
 	else
 		hipLaunchKernelGGL(sai2b::range_cert_kernel<6>, grid, block, 0, stream, d_params, rg_counts, rg_list, parity);
+	return (int)hipGetLastError();
+}
+
+extern "C" int sai2b_launch_task_cert(const sai2b::DevParams* d_params, int B, int task, int max_rows, const double* Nprec_in,
+									  const double* tau_prec, double* tau_out, double* N_out, double* Ntot_out, int do_torque, int* tk_count,
+									  int* tk_list, hipStream_t stream) {
+	const dim3 grid((B + 63) / 64), block(64);
+	if (hipMemsetAsync(tk_count, 0, sizeof(int), stream) != hipSuccess) return 1;
+	if (max_rows <= 3)
+		hipLaunchKernelGGL(sai2b::task_cert_kernel<3>, grid, block, 0, stream, d_params, task, Nprec_in, tau_prec, tau_out, N_out, Ntot_out,
+						   do_torque, tk_count, tk_list);
+	else
+		hipLaunchKernelGGL(sai2b::task_cert_kernel<6>, grid, block, 0, stream, d_params, task, Nprec_in, tau_prec, tau_out, N_out, Ntot_out,
+						   do_torque, tk_count, tk_list);
 	return (int)hipGetLastError();
 }
 

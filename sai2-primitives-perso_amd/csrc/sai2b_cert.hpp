@@ -473,8 +473,22 @@ DI void mul_llt(const real* L, const real* x, real* y) {
 // Returns whether every task was certified (and no MotionForceTask is inside / leaving a singular region): only
 // then may the caller flush the deferred stores and write tau.
 // MD: where the robot constants come from (the parameter block, or the compile-time Panda of sai2b_baked_panda.h)
-template <int MCAP, int DCAP, class MD>
-DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, real* pend, real* tau) {
+// TASK = true: the TemplateTask calls on ONE task under a caller-supplied N_prec (TemplateTask.h:42-88; round 3). The
+// cascade needs N_prec in whitened form, N_prec = L^-T Q L^T with Q an orthogonal projector: Q = L^T N_prec L^-T is
+// computed and CHECKED (symmetric and idempotent to 1e-9, integer trace) — every dynamically consistent nullspace a
+// chain of these calls produces passes, anything else sends the robot to the generic kernel like an uncertified level.
+// Outputs besides the torques: the task's nullspace N = L^-T (I - Q0 + Q1) L^T and N N_prec = L^-T Q1 L^T.
+struct TaskArgs {
+	int task;
+	const real* Nprec;	   // [N * N][B], NULL: the identity a task is constructed with (JointTask.cpp:62, MotionForceTask.cpp:138)
+	const real* tau_prec;  // [N][B] or NULL (the no-argument computeTorques)
+	real* N_out;		   // [N * N][B] or NULL
+	real* Ntot_out;		   // [N * N][B] or NULL
+	real* q0;			   // this lane's column of an LDS area of N (N + 1) / 2 doubles (stride 64): Q before the level
+};
+
+template <int MCAP, int DCAP, class MD, bool TASK = false>
+DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, real* pend, real* tau, const TaskArgs* io = nullptr) {
 	CSTAMP(0);
 	Fact f;
 	bool ok = true;
@@ -516,10 +530,51 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 	UNROLL for (int i = 0; i < N * N; i++) Q[i] = (i % (N + 1) == 0) ? 1.0 : 0.0;
 	UNROLL for (int i = 0; i < N; i++) tau[i] = 0;
 	int wrows = 0;	// rows of the certified tasks so far (batch-uniform)
+	bool task_first = true;	 // TASK: N_prec is the identity
+	if constexpr (TASK) {
+		if (io->tau_prec) {
+			UNROLL for (int i = 0; i < N; i++) tau[i] = ld(io->tau_prec, i, B, b);
+		}
+		if (io->Nprec) {
+			// Q = L^T N_prec L^-T, row by row: A = L^T N_prec, then L Q[i, :]^T = A[i, :]^T
+			real Np[N * N], Qf[N * N];
+			UNROLL for (int i = 0; i < N * N; i++) Np[i] = ld(io->Nprec, i, B, b);
+			UNROLL for (int i = 0; i < N; i++) {
+				real row[N];
+				UNROLL for (int j = 0; j < N; j++) {
+					real s = 0;
+					UNROLL for (int k = i; k < N; k++) s = fma(f.L[k * N + i], Np[k * N + j], s);
+					row[j] = s;
+				}
+				solve_lower<N>(f.L, f.dL, row);
+				UNROLL for (int j = 0; j < N; j++) Qf[i * N + j] = row[j];
+			}
+			real asym = 0, tr = 0;
+			UNROLL for (int i = 0; i < N; i++) {
+				tr += Qf[i * N + i];
+				UNROLL for (int j = 0; j < i; j++) {
+					asym = fmax(asym, fabs(Qf[i * N + j] - Qf[j * N + i]));
+					Qf[i * N + j] = Qf[j * N + i] = 0.5 * (Qf[i * N + j] + Qf[j * N + i]);
+				}
+			}
+			real idem = 0;
+			UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) {
+				real s = -Qf[i * N + j];
+				UNROLL for (int k = 0; k < N; k++) s = fma(Qf[i * N + k], Qf[k * N + j], s);
+				idem = fmax(idem, fabs(s));
+			}
+			const int rk = (int)(tr + 0.5);
+			ok = ok && asym < 1e-9 && idem < 1e-9 && fabs(tr - (real)rk) < 1e-6 && rk >= 0 && rk <= N;	 // (NaNs fail too)
+			wrows = (rk >= 0 && rk <= N) ? N - rk : 0;
+			task_first = wrows == 0;  // an N_prec that IS the identity
+			UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) Q[i * N + j] = Qf[i * N + j];
+		}
+		UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) io->q0[(i * (i + 1) / 2 + j) * 64] = Q[i * N + j];
+	}
 #pragma unroll 1
-	for (int ti = 0; ti < P.n_tasks; ti++) {
+	for (int ti = (TASK ? io->task : 0); ti < (TASK ? io->task + 1 : P.n_tasks); ti++) {
 		const DevTask& t = P.task[ti];
-		const bool first = (ti == 0), last = (ti == P.n_tasks - 1);
+		const bool first = TASK ? task_first : (ti == 0), last = TASK ? false : (ti == P.n_tasks - 1);
 		if (t.type == SAI2B_MOTION_FORCE_TASK) {
 			// MotionForceTask::updateTaskModel / computeTorques (MotionForceTask.cpp:247-509) in the fully
 			// non-singular branch of the SingularityHandler (SingularityHandler.cpp:100-141,307-309)
@@ -592,7 +647,7 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 						dq[i] = ld(P.dq, i, B, b);
 					}
 					UNROLL for (int i = 0; i < N; i++) comp[i] = 0;
-					if (with_comp && !first) {	// JointTask.cpp:285-292: S M^-1 tau_prec
+					if (with_comp && (!first || TASK)) {	// JointTask.cpp:285-292: S M^-1 tau_prec
 						real u[N];
 						UNROLL for (int i = 0; i < N; i++) u[i] = tau[i];
 						solve_lower<N>(f.L, f.dL, u);
@@ -668,7 +723,47 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 		if (wrows > N) wrows = N;
 		CSTAMP(40);
 	}
+	if constexpr (TASK) {
+		// getTaskNullspace / getTaskAndPreviousNullspace (TemplateTask.h:73-88) of a robot that finishes here: X = L^-T S L^T
+		// for S = I - Q0 + Q1 and S = Q1, column by column (T[:, j] = S L^T e_j, then L^T X[:, j] = T[:, j])
+		if (ok) {
+			UNROLL for (int which = 0; which < 2; which++) {
+				real* out = which ? io->Ntot_out : io->N_out;
+				if (!out) continue;
+				real S[N * N];
+				UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) {
+					const real q1 = Q[i * N + j];
+					S[i * N + j] = which ? q1 : ((i == j ? 1.0 : 0.0) - io->q0[(i * (i + 1) / 2 + j) * 64] + q1);
+				}
+				UNROLL for (int j = 0; j < N; j++) {
+					real col[N];
+					UNROLL for (int i = 0; i < N; i++) {
+						real s = 0;
+						UNROLL for (int k = 0; k <= j; k++) s = fma(symat(S, i, k), f.L[j * N + k], s);
+						col[i] = s;
+					}
+					solve_lower_t<N>(f.L, f.dL, col);
+					UNROLL for (int i = 0; i < N; i++) st(out, i * N + j, B, b, col[i]);
+				}
+			}
+		}
+	}
 	return ok;
+}
+
+// TASK: write the deferred integrators of the one task that ran (slots from N on, as tick() filled them)
+DI void flush_task(const DevParams& P, int task, int B, int b, const real* pend) {
+	const DevTask& t = P.task[task];
+	const int np = N;
+	if (t.type == SAI2B_MOTION_FORCE_TASK) {
+		for (int k = 0; k < 6; k++) st(t.state, k, B, b, pend[(np + k) * 64]);
+		if (t.cl_force)
+			for (int k = 6; k < 9; k++) st(t.state, k, B, b, pend[(np + k) * 64]);
+		if (t.cl_moment)
+			for (int k = 9; k < 12; k++) st(t.state, k, B, b, pend[(np + k) * 64]);
+	} else {
+		for (int k = 0; k < t.k0; k++) st(t.state, k, B, b, pend[(np + k) * 64]);
+	}
 }
 
 // The range pass ahead of the trajectory generators for the robots this kernel family can vouch for: a JointTask whose

@@ -89,6 +89,9 @@ struct sai2b_ctx {
 	double* sim_tau = nullptr;	// staging for host torques / bias read-back of the simulation harness
 	// task-level calls (TemplateTask.h:42-88): per task the caller's N_prec, the task's N and N * N_prec of the
 	// last sai2b_task_update_model, its torques and a staging copy of a host tau_prec; created on first use
+	int* tk_count = nullptr;  // work list of the task-level SVD-free kernel (task_cert_kernel): 1 counter + B robot indices
+	int* tk_list = nullptr;
+	bool no_task_cert = false;	// SAI2B_NO_TASK_CERT=1: the generic task_kernel for every robot (A/B)
 	struct TaskIO {
 		double *Nprec = nullptr, *N = nullptr, *Ntot = nullptr, *tau = nullptr, *tau_prec = nullptr;
 		bool nprec_given = false;  // false: identity (the value a task is constructed with)
@@ -654,6 +657,8 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	ctx->blocking_sync = bs && bs[0] == '1';
 	const char* nc = std::getenv("SAI2B_NO_CERT_PATH");
 	ctx->no_cert_path = nc && nc[0] == '1';
+	const char* ntc = std::getenv("SAI2B_NO_TASK_CERT");
+	ctx->no_task_cert = ntc && ntc[0] == '1';
 	const char* pc = std::getenv("SAI2B_PREFER_CERT");
 	ctx->prefer_cert = pc && pc[0] == '1';
 	if (const char* gl = std::getenv("SAI2B_GENERIC_LANES")) ctx->generic_lanes_env = std::atoi(gl);
@@ -1225,6 +1230,44 @@ static int task_io(sai2b_ctx* ctx, int task, const char* fn) {
 	return SAI2B_OK;
 }
 
+// Rows of a task when the SVD-free task-level kernel (sai2b_cert.hip: task_cert_kernel) can serve it, else 0: the
+// eligibility of cert_kind() for this one task. Not with introspection (its outputs come from the generic kernel) nor
+// a passivity observer (it mutates state inside the law).
+static int task_cert_rows(const sai2b_ctx* ctx, int task) {
+	if (ctx->no_task_cert || ctx->no_fast_path || ctx->no_cert_path || ctx->introspection) return 0;
+	const DevTask& d = ctx->h_params.task[task];
+	if (d.type == SAI2B_MOTION_FORCE_TASK) {
+		if (ctx->cfg[task].passivity_enabled && ctx->cfg[task].closed_loop_force) return 0;
+		return (d.rank >= 1 && d.rank <= 6) ? d.rank : 0;
+	}
+	if (d.full_selection) return 1;	 // (a full JointTask brings no level of its own: the small instantiation)
+	return d.k0 <= 6 ? d.k0 : 0;
+}
+// one TemplateTask call on the device: the SVD-free kernel with the generic one over the robots it declined, or the
+// generic one for every robot
+static int launch_task_call(sai2b_ctx* ctx, int task, const double* Np, const double* tp, double* tau_out, double* N_out, double* Ntot_out,
+							int commit_sh, int do_torque) {
+	const int rows = task_cert_rows(ctx, task);
+	if (rows) {
+		if (!ctx->tk_count) {
+			int rc;
+			if ((rc = dev_alloc(ctx, &ctx->tk_count, 1))) return rc;
+			if ((rc = dev_alloc(ctx, &ctx->tk_list, (size_t)ctx->B))) return rc;
+		}
+		if (sai2b_launch_task_cert(ctx->d_params, ctx->B, task, rows, Np, tp, tau_out, N_out, Ntot_out, do_torque, ctx->tk_count, ctx->tk_list,
+								   ctx->stream) ||
+			sai2b_launch_task(ctx->d_params, ctx->B, task, Np, tp, tau_out, N_out, Ntot_out, commit_sh, do_torque, ctx->tk_count, ctx->tk_list,
+							  ctx->stream))
+			return set_error(ctx, SAI2B_RUNTIME_ERROR, "task launch failed");
+		ctx->launches += 2;
+		return SAI2B_OK;
+	}
+	if (sai2b_launch_task(ctx->d_params, ctx->B, task, Np, tp, tau_out, N_out, Ntot_out, commit_sh, do_torque, nullptr, nullptr, ctx->stream))
+		return set_error(ctx, SAI2B_RUNTIME_ERROR, "task launch failed");
+	ctx->launches++;
+	return SAI2B_OK;
+}
+
 extern "C" int sai2b_task_update_model(sai2b_ctx* ctx, int task, const double* N_prec, int on_device) {
 	int rc = task_io(ctx, task, "sai2b_task_update_model");
 	if (rc) return rc;
@@ -1233,10 +1276,8 @@ extern "C" int sai2b_task_update_model(sai2b_ctx* ctx, int task, const double* N
 	if ((rc = copy_rows(ctx, io.Nprec, N_prec, N * N, on_device))) return rc;
 	refresh_otg_gating(ctx);
 	if ((rc = upload_params(ctx))) return rc;
-	if (sai2b_launch_task(ctx->d_params, ctx->B, task, io.nprec_given ? io.Nprec : nullptr, nullptr, nullptr, io.N, io.Ntot,
-						  /*commit_sh=*/1, /*do_torque=*/0, ctx->stream))
-		return set_error(ctx, SAI2B_RUNTIME_ERROR, "task model launch failed");
-	ctx->launches++;
+	if ((rc = launch_task_call(ctx, task, io.nprec_given ? io.Nprec : nullptr, nullptr, nullptr, io.N, io.Ntot, /*commit_sh=*/1, /*do_torque=*/0)))
+		return rc;
 	io.model_fresh = true;
 	return SAI2B_OK;
 }
@@ -1252,7 +1293,7 @@ extern "C" int sai2b_task_compute_torques(sai2b_ctx* ctx, int task, const double
 	if (d.otg_on) {	 // the task's generator advances once per torque computation, before the law
 		if (((gated >> task) & 1) && !io.model_fresh) {
 			// is the JointTask's range empty for this robot now (JointTask.cpp:302-306)? models of the current state, nothing committed
-			if (sai2b_launch_task(ctx->d_params, ctx->B, task, Np, nullptr, nullptr, io.N, io.Ntot, 0, 0, ctx->stream))
+			if (sai2b_launch_task(ctx->d_params, ctx->B, task, Np, nullptr, nullptr, io.N, io.Ntot, 0, 0, nullptr, nullptr, ctx->stream))
 				return set_error(ctx, SAI2B_RUNTIME_ERROR, "task-range pass launch failed");
 			ctx->launches++;
 		}
@@ -1271,9 +1312,7 @@ extern "C" int sai2b_task_compute_torques(sai2b_ctx* ctx, int task, const double
 		if ((rc = copy_rows(ctx, io.tau_prec, tau_prec, N, 0))) return rc;
 		tp = io.tau_prec;
 	}
-	if (sai2b_launch_task(ctx->d_params, ctx->B, task, Np, tp, io.tau, io.N, io.Ntot, io.model_fresh ? 0 : 1, 1, ctx->stream))
-		return set_error(ctx, SAI2B_RUNTIME_ERROR, "task torque launch failed");
-	ctx->launches++;
+	if ((rc = launch_task_call(ctx, task, Np, tp, io.tau, io.N, io.Ntot, io.model_fresh ? 0 : 1, 1))) return rc;
 	ctx->ticks += ctx->B;
 	io.model_fresh = false;
 	ctx->q_is_pose = true;	// computeTorques caches the task's current pose

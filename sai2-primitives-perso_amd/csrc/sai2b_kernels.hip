@@ -198,13 +198,18 @@ __global__ __launch_bounds__(64) void tick_fast_kernel(const DevParams* __restri
 // compensation term also behind an identity N_prec, as JointTask::computeTorques(tau_prec) does
 // (JointTask.cpp:285-292). Used for examples 01 / 04 / 18-style manual hierarchies; the batched hot path is
 // the fused tick above.
+// tk_count != NULL: the pass behind task_cert_kernel (sai2b_cert.hip) over the robots it declined, compacted.
 __global__ __launch_bounds__(64) void task_kernel(const DevParams* __restrict__ Pp, int task, const double* __restrict__ Nprec_in,
 													 const double* __restrict__ tau_prec, double* __restrict__ tau_out,
 													 double* __restrict__ N_out, double* __restrict__ Ntot_out, int commit_sh,
-													 int do_torque) {
+													 int do_torque, const int* __restrict__ tk_count, const int* __restrict__ tk_list) {
 	const DevParams& P = *Pp;
 	const int B = P.B;
-	const int b = blockIdx.x * 64 + threadIdx.x;
+	int b = blockIdx.x * 64 + threadIdx.x;
+	if (tk_count) {
+		if (b >= *(const gint*)tk_count) return;
+		b = ((const gint*)tk_list)[b];
+	}
 	if (b >= B) return;
 	RobotCtx rc;
 	UNROLL for (int i = 0; i < N; i++) {
@@ -364,8 +369,9 @@ extern "C" int sai2b_launch_reinit(const sai2b::DevParams* d_params, int B, int 
 }
 
 extern "C" int sai2b_launch_task(const sai2b::DevParams* d_params, int B, int task, const double* Nprec_in, const double* tau_prec,
-								 double* tau_out, double* N_out, double* Ntot_out, int commit_sh, int do_torque, hipStream_t stream) {
+								 double* tau_out, double* N_out, double* Ntot_out, int commit_sh, int do_torque, const int* tk_count,
+								 const int* tk_list, hipStream_t stream) {
 	hipLaunchKernelGGL(sai2b::task_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, d_params, task, Nprec_in, tau_prec, tau_out, N_out,
-					   Ntot_out, commit_sh, do_torque);
+					   Ntot_out, commit_sh, do_torque, tk_count, tk_list);
 	return (int)hipGetLastError();
 }

@@ -17,6 +17,8 @@
 // divergent lane in every wavefront.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "sai2b_device.hpp"
 #include "sai2b_launch.h"
 #if SAI2B_N > 7
@@ -437,7 +439,113 @@ DI void plan_group(const DevTask& t, bool cart, int n, int B, int b) {
 	}
 }
 
-// PLAN for a JERK-LIMITED generator, one lane per robot: setGoal...(goal); update(); with ruckig's third-order
+// PLAN for a JERK-LIMITED generator, one DoF per lane (sai2b_otg_group.hpp: LaneGen3, calculate3): the counterpart of
+// plan_group for ruckig's third-order interface. The stored profile of the lane's DoF travels through otg3_traj.
+DI void plan_group3(const DevTask& t, bool cart, int n, int B, int b) {
+	using namespace otgg;
+	real* S = t.otg_state;
+	real* T3 = t.otg3_traj;
+	const int j = lane_j();
+	const bool active = j < n;
+	auto row = [&](int r0) { return active ? ld(S, r0 + j, B, b) : 0.0; };
+	LaneGen3 g;
+	g.in_cp = row(OTG_IN), g.in_cv = row(OTG_IN + MD), g.in_ca = row(OTG_IN + 2 * MD), g.in_tp = row(OTG_IN + 3 * MD),
+	g.in_tv = row(OTG_IN + 4 * MD);
+	g.ci_cp = row(OTG_CI), g.ci_cv = row(OTG_CI + MD), g.ci_ca = row(OTG_CI + 2 * MD), g.ci_tp = row(OTG_CI + 3 * MD),
+	g.ci_tv = row(OTG_CI + 4 * MD);
+	g.np = row(OTG_OUT), g.nv = row(OTG_OUT + MD), g.na = row(OTG_OUT + 2 * MD);
+	if (ldflag(S, OTG_IN_SYNC, B, b) != 0) {  // see OTG_IN_SYNC
+		g.in_cp = g.ci_cp = g.np, g.in_cv = g.ci_cv = g.nv, g.in_ca = g.ci_ca = g.na;
+		g.ci_tp = g.in_tp, g.ci_tv = g.in_tv;
+	}
+	{	// the stored third-order profile of this lane's DoF (sampled when no new calculation is needed)
+		const int r = (active ? j : 0) * OTG3_STRIDE;
+		otg3::Prof& p = g.p;
+		p.brake.duration = ld(T3, r + OTG3_BRAKE, B, b);
+		UNROLL for (int k = 0; k < 2; k++) {
+			p.brake.t[k] = ld(T3, r + OTG3_BRAKE + 1 + k, B, b), p.brake.j[k] = ld(T3, r + OTG3_BRAKE + 3 + k, B, b);
+			p.brake.a[k] = ld(T3, r + OTG3_BRAKE + 5 + k, B, b), p.brake.v[k] = ld(T3, r + OTG3_BRAKE + 7 + k, B, b);
+			p.brake.p[k] = ld(T3, r + OTG3_BRAKE + 9 + k, B, b);
+		}
+		UNROLL for (int k = 0; k < 7; k++) p.t_sum[k] = ld(T3, r + OTG3_TSUM + k, B, b), p.j[k] = ld(T3, r + OTG3_J + k, B, b), p.t[k] = 0;
+		UNROLL for (int k = 0; k < 8; k++) p.a[k] = ld(T3, r + OTG3_A + k, B, b), p.v[k] = ld(T3, r + OTG3_V + k, B, b), p.p[k] = ld(T3, r + OTG3_P + k, B, b);
+		p.pf = p.vf = p.af = 0, p.limits = p.direction = p.control_signs = 0;
+	}
+	g.time = ld(S, OTG_TIME, B, b);
+	g.duration = ld(S, OTG_DURATION, B, b);
+	g.goal_reached = ldflag(S, OTG_GOAL_REACHED, B, b);
+	g.result = ldflag(S, OTG_RESULT, B, b);
+	g.target_set = ldflag(S, OTG_TARGET_SET, B, b);
+	g.ci_init = ldflag(S, OTG_CI_INIT, B, b);
+	g.ci_epoch = ld(S, OTG_CI_EPOCH, B, b);
+	g.replanned = 0;
+	const double vmax = active ? sel7(t.otg_vmax, j) : 0.0, amax = active ? sel7(t.otg_amax, j) : 0.0;
+	g.jmax = active ? sel7(t.otg_jmax, j) : 0.0;
+	if (cart) {
+		UNROLL for (int i = 0; i < 9; i++) g.ref[i] = ld(S, OTG_CART + i, B, b), g.goal_R[i] = ld(S, OTG_CART + 9 + i, B, b);
+		UNROLL for (int i = 0; i < 3; i++) g.goal_w[i] = ld(S, OTG_CART + 18 + i, B, b);
+		real gR[9], gw[3];
+		UNROLL for (int k = 0; k < 9; k++) gR[k] = ld(t.goals, 3 + k, B, b);
+		UNROLL for (int k = 0; k < 3; k++) gw[k] = ld(t.goals, 15 + k, B, b);
+		const double gp = j < 3 ? ld(t.goals, j, B, b) : 0.0, gv = j < 3 ? ld(t.goals, 12 + j, B, b) : 0.0;
+		cart_set_goal_position(g, gp, gv);
+		cart_set_goal_orientation(g, gR, gw);
+	} else {
+		const double gp = active ? ld(t.goals, j, B, b) : 0.0, gv = active ? ld(t.goals, n + j, B, b) : 0.0;
+		joints_set_goal(g, active, n, gp, gv);
+	}
+	update(g, cart, active, n, t.dt, vmax, amax, t.otg_epoch);
+
+	auto put = [&](int r0, double v) {
+		if (active) st(S, r0 + j, B, b, v);
+	};
+	put(OTG_IN, g.in_cp), put(OTG_IN + MD, g.in_cv), put(OTG_IN + 2 * MD, g.in_ca), put(OTG_IN + 3 * MD, g.in_tp), put(OTG_IN + 4 * MD, g.in_tv);
+	put(OTG_CI, g.ci_cp), put(OTG_CI + MD, g.ci_cv), put(OTG_CI + 2 * MD, g.ci_ca), put(OTG_CI + 3 * MD, g.ci_tp), put(OTG_CI + 4 * MD, g.ci_tv);
+	put(OTG_OUT, g.np), put(OTG_OUT + MD, g.nv), put(OTG_OUT + 2 * MD, g.na);
+	if (g.replanned && active) {
+		const otg3::Prof& p = g.p;
+		const int r = j * OTG3_STRIDE;
+		st(T3, r + OTG3_BRAKE, B, b, p.brake.duration);
+		UNROLL for (int k = 0; k < 2; k++) {
+			st(T3, r + OTG3_BRAKE + 1 + k, B, b, p.brake.t[k]), st(T3, r + OTG3_BRAKE + 3 + k, B, b, p.brake.j[k]);
+			st(T3, r + OTG3_BRAKE + 5 + k, B, b, p.brake.a[k]), st(T3, r + OTG3_BRAKE + 7 + k, B, b, p.brake.v[k]);
+			st(T3, r + OTG3_BRAKE + 9 + k, B, b, p.brake.p[k]);
+		}
+		UNROLL for (int k = 0; k < 7; k++) st(T3, r + OTG3_TSUM + k, B, b, p.t_sum[k]), st(T3, r + OTG3_J + k, B, b, p.j[k]);
+		UNROLL for (int k = 0; k < 8; k++) st(T3, r + OTG3_A + k, B, b, p.a[k]), st(T3, r + OTG3_V + k, B, b, p.v[k]), st(T3, r + OTG3_P + k, B, b, p.p[k]);
+	}
+	real R[9], w[3], al[3];
+	if (cart) {
+		real local[9];
+		otg::vec_to_rot(gget(g.np, 3), gget(g.np, 4), gget(g.np, 5), local);
+		otg::mat3_mul(g.ref, local, R);
+		otg::mat3_vec(g.ref, gget(g.nv, 3), gget(g.nv, 4), gget(g.nv, 5), w);
+		otg::mat3_vec(g.ref, gget(g.na, 3), gget(g.na, 4), gget(g.na, 5), al);
+	}
+	if (j == 0) {
+		st(S, OTG_TIME, B, b, g.time);
+		if (g.replanned) st(S, OTG_DURATION, B, b, g.duration);
+		st(S, OTG_GOAL_REACHED, B, b, (double)g.goal_reached);
+		st(S, OTG_RESULT, B, b, (double)g.result);
+		st(S, OTG_TARGET_SET, B, b, (double)g.target_set);
+		st(S, OTG_CI_INIT, B, b, (double)g.ci_init);
+		st(S, OTG_CI_EPOCH, B, b, g.ci_epoch);
+		st(S, OTG_IN_SYNC, B, b, 0.0);
+		if (cart) {
+			UNROLL for (int i = 0; i < 9; i++) st(S, OTG_CART + i, B, b, g.ref[i]), st(S, OTG_CART + 9 + i, B, b, g.goal_R[i]);
+			UNROLL for (int i = 0; i < 3; i++) st(S, OTG_CART + 18 + i, B, b, g.goal_w[i]);
+			UNROLL for (int k = 0; k < 9; k++) st(t.otg_desired, 3 + k, B, b, R[k]);
+			UNROLL for (int k = 0; k < 3; k++) st(t.otg_desired, 15 + k, B, b, w[k]), st(t.otg_desired, 21 + k, B, b, al[k]);
+		}
+	}
+	if (cart) {
+		if (j < 3) st(t.otg_desired, j, B, b, g.np), st(t.otg_desired, 12 + j, B, b, g.nv), st(t.otg_desired, 18 + j, B, b, g.na);
+	} else if (active && !t.otg_out_is_desired) {
+		st(t.otg_desired, j, B, b, g.np), st(t.otg_desired, n + j, B, b, g.nv), st(t.otg_desired, 2 * n + j, B, b, g.na);
+	}
+}
+
+// PLAN for a JERK-LIMITED generator, one lane per robot (kept as the A/B partner of plan_group3: SAI2B_OTG3_ONE_LANE=1): setGoal...(goal); update(); with ruckig's third-order
 // interface (sai2b_otg3_core.hpp), DoF after DoF out of this lane's scratch memory. The wrapper state travels through
 // the same rows as for the acceleration-limited generator (load_head / load_body / store_state); only the stored
 // trajectory differs (otg3_traj).
@@ -569,19 +677,31 @@ __global__ __launch_bounds__(64) void otg_plan_kernel(const DevParams* __restric
 // The listed robots of the JERK-LIMITED generators, one lane each (plan_lane3). Launched behind otg_plan_kernel only
 // while some task is jerk-limited; a small grid striding over the lists bounds the scratch memory the third-order
 // planner needs per lane (~20 KB: seven DoFs of blocks, each with up to three stored profiles).
+template <bool ONE_LANE>
 __global__ __launch_bounds__(64) void otg3_plan_kernel(const DevParams* __restrict__ Pp, const int* __restrict__ counts,
 													   const int* __restrict__ list, int parity, int task_mask) {
 	const DevParams& P = *Pp;
 	const int B = P.B;
+	constexpr int GROUPS = 64 / otgg::G;
 #pragma unroll 1
 	for (int t = 0; t < P.n_tasks; t++) {
 		const DevTask& tk = P.task[t];
 		if (!tk.otg_on || !tk.otg_jerk || !((task_mask >> t) & 1)) continue;
 		const int cnt = ((const gint*)counts)[parity * SAI2B_MAX_TASKS + t];
+		if constexpr (ONE_LANE) {
 #pragma unroll 1
-		for (int e = blockIdx.x * 64 + threadIdx.x; e < cnt; e += gridDim.x * 64) {
-			const int b = ((const gint*)list)[(size_t)t * B + e];
-			plan_lane3(tk, tk.type == SAI2B_MOTION_FORCE_TASK, tk.otg_n, B, b);
+			for (int e = blockIdx.x * 64 + threadIdx.x; e < cnt; e += gridDim.x * 64) {
+				const int b = ((const gint*)list)[(size_t)t * B + e];
+				plan_lane3(tk, tk.type == SAI2B_MOTION_FORCE_TASK, tk.otg_n, B, b);
+			}
+		} else {
+#pragma unroll 1
+			for (int e0 = blockIdx.x * GROUPS; e0 < cnt; e0 += gridDim.x * GROUPS) {  // uniform over the wavefront
+				const int e = e0 + threadIdx.x / otgg::G;
+				if (e >= cnt) continue;	 // uniform over the group
+				const int b = ((const gint*)list)[(size_t)t * B + e];
+				plan_group3(tk, tk.type == SAI2B_MOTION_FORCE_TASK, tk.otg_n, B, b);
+			}
 		}
 	}
 }
@@ -726,9 +846,16 @@ extern "C" int sai2b_launch_otg(const sai2b::DevParams* d_params, int B, int* co
 	const int plan_blocks = (B + 7) / 8 < 2048 ? (B + 7) / 8 : 2048;
 	hipLaunchKernelGGL(sai2b::otg_plan_kernel, dim3(plan_blocks), block, 0, stream, d_params, counts, (const int*)list, parity, task_mask);
 	if (jerk_mask & task_mask) {
-		const int blocks3 = (B + 63) / 64 < 256 ? (B + 63) / 64 : 256;
-		hipLaunchKernelGGL(sai2b::otg3_plan_kernel, dim3(blocks3), block, 0, stream, d_params, (const int*)counts, (const int*)list, parity,
-						   task_mask);
+		static const bool one_lane = std::getenv("SAI2B_OTG3_ONE_LANE") != nullptr;	 // A/B: round 3's first planner, one lane per robot
+		if (one_lane) {
+			const int blocks3 = (B + 63) / 64 < 256 ? (B + 63) / 64 : 256;
+			hipLaunchKernelGGL(sai2b::otg3_plan_kernel<true>, dim3(blocks3), block, 0, stream, d_params, (const int*)counts, (const int*)list,
+							   parity, task_mask);
+		} else {  // one DoF per lane; the grid strides over the list and bounds the scratch (one block of profiles per lane)
+			const int blocks3 = (B + 7) / 8 < 1024 ? (B + 7) / 8 : 1024;
+			hipLaunchKernelGGL(sai2b::otg3_plan_kernel<false>, dim3(blocks3), block, 0, stream, d_params, (const int*)counts, (const int*)list,
+							   parity, task_mask);
+		}
 	}
 	return hipGetLastError() == hipSuccess ? 0 : 1;
 }

@@ -15,6 +15,7 @@
 #pragma once
 #include "sai2b_device.hpp"
 #include "sai2b_otg_core.hpp"
+#include "sai2b_otg3_core.hpp"
 
 namespace sai2b {
 namespace otgg {
@@ -210,6 +211,184 @@ DI int calculate(bool active, int n, double cp, double cv, double ca, double tp,
 	return gany(bad) ? otg::ERR_SYNCHRONIZATION : otg::WORKING;
 }
 
+// ---- the jerk-limited generator, one DoF per lane (round 3): the per-DoF planner is sai2b_otg3_core.hpp's (brake, step 1,
+// step 2, check, sampling: the code whose host build is bit-equal to the reference's ruckig), the couplings between the
+// DoFs are the same shuffles and ballots as above on the third-order profile ----
+struct LaneGen3 {
+	double in_cp, in_cv, in_ca, in_tp, in_tv;
+	double ci_cp, ci_cv, ci_ca, ci_tp, ci_tv;
+	double np, nv, na;
+	otg3::Prof p;
+	double jmax;
+	// uniform over the group
+	double time, duration, ci_epoch;
+	int goal_reached, result, target_set, ci_init, replanned;
+	double ref[9], goal_R[9], goal_w[3];
+};
+
+// TargetCalculator::calculate (calculator_target.hpp:236-532) for finite max_jerk, one DoF per lane
+__device__ __noinline__ int calculate3(bool active, int n, double cp, double cv, double ca, double tp, double tv, double vmax, double amax,
+									   double jmax, otg3::Prof& p, double& duration) {
+	const int j = lane_j();
+	otg3::Block bl;
+	bl.a = bl.b = false;
+	bl.tmin = 0;
+	bool ok1 = true;
+	if (active) {
+		otg3::position_brake(p.brake, cv, ca, vmax, -vmax, amax, -amax, jmax);
+		p.p[0] = cp, p.v[0] = cv, p.a[0] = ca, p.pf = tp, p.vf = tv, p.af = 0.0;
+		otg3::brake_finalize(p.brake, p.p[0], p.v[0], p.a[0]);
+		ok1 = otg3::step1(p, bl, vmax, -vmax, amax, -amax, jmax);
+	}
+	if (gany(active && !ok1)) return gany(active && !ok1 && (amax == 0.0 || jmax == 0.0)) ? otg::ERR_ZERO_LIMITS : otg::ERR_EXECUTION_TIME;
+	if (n == 1) {
+		duration = gget(bl.tmin, 0);
+		if (j == 0) p = bl.pmin;
+		return otg::WORKING;
+	}
+	// synchronize (calculator_target.hpp:120-222), as in calculate() above
+	const double c0 = active ? bl.tmin : INFINITY, c1 = (active && bl.a) ? bl.aright : INFINITY, c2 = (active && bl.b) ? bl.bright : INFINITY;
+	const bool any_interval = gany(active && (bl.a || bl.b));
+	double cand[3][G];
+	UNROLL for (int d = 0; d < G; d++) {
+		cand[0][d] = gget(c0, d);
+		cand[1][d] = gget(c1, d);
+		cand[2][d] = gget(c2, d);
+	}
+	int blocked = 0;
+	UNROLL for (int q = 0; q < 3; q++)
+		UNROLL for (int d = 0; d < G; d++)
+			if (active && otg3::is_blocked(bl, cand[q][d])) blocked |= 1 << (q * G + d);
+	blocked = gor(blocked);
+	int best_rank = 1 << 20, best_q = -1, best_d = -1;
+	UNROLL for (int q = 0; q < 3; q++)
+		UNROLL for (int d = 0; d < G; d++) {
+			if (d >= n || (!any_interval && q > 0)) continue;
+			const double t = cand[q][d];
+			int rank = 0;
+			UNROLL for (int oq = 0; oq < 3; oq++)
+				UNROLL for (int od = 0; od < G; od++) {
+					if (od >= n || (!any_interval && oq > 0)) continue;
+					const bool before = (oq < q) || (oq == q && od < d);
+					if (cand[oq][od] < t || (cand[oq][od] == t && before)) rank++;
+				}
+			if (rank < n - 1 || rank >= best_rank) continue;
+			if (((blocked >> (q * G + d)) & 1) || t < 0.0 || isinf(t)) continue;
+			best_rank = rank, best_q = q, best_d = d;
+		}
+	if (best_d < 0) return otg::ERR_SYNCHRONIZATION;
+	const int limiting = best_d;
+	{
+		double t = 0;
+		UNROLL for (int q = 0; q < 3; q++)
+			UNROLL for (int d = 0; d < G; d++)
+				if (q == best_q && d == best_d) t = cand[q][d];
+		duration = t;
+	}
+	if (j == limiting) p = best_q == 0 ? bl.pmin : best_q == 1 ? bl.aprof : bl.bprof;
+	if (duration > 7.6e3) return otg::ERR_TRAJECTORY_DURATION;
+	if (duration == 0.0) {
+		if (active) p = bl.pmin;
+		return otg::WORKING;
+	}
+	// phase synchronisation (calculator_target.hpp:398-467), collinearity test :46-118 with the jerk as control
+	{
+		double plt[7];
+		UNROLL for (int i = 0; i < 7; i++) plt[i] = gget(p.t[i], limiting);
+		const int pl_dir = ggeti(p.direction, limiting), pl_cs = ggeti(p.control_signs, limiting), pl_lim = ggeti(p.limits, limiting);
+		const double pd = tp - cp;
+		int which = -1;
+		if (active) {
+			if (fabs(pd) > otg::EPS)
+				which = 0;
+			else if (fabs(cv) > otg::EPS)
+				which = 1;
+			else if (fabs(ca) > otg::EPS)
+				which = 2;
+			else if (fabs(tv) > otg::EPS)
+				which = 3;
+		}
+		const unsigned has = gbits(which >= 0);
+		if (has) {
+			const int scale_dof = __ffs((int)has) - 1;
+			const int w = ggeti(which, scale_dof);
+			const double sv = w == 0 ? pd : w == 1 ? cv : w == 2 ? ca : tv;
+			const double scale = gget(sv, scale_dof);
+			const double pd_scale = gget(pd, scale_dof) / scale, v0_scale = gget(cv, scale_dof) / scale,
+						 vf_scale = gget(tv, scale_dof) / scale, a0_scale = gget(ca, scale_dof) / scale, af_scale = 0.0 / scale;
+			const double scale_limiting = gget(sv, limiting);
+			const double jmax_lim = gget(jmax, limiting);
+			const double control_limiting = (pl_dir == otg3::UP) ? jmax_lim : -jmax_lim;
+			const bool off = active && (fabs(pd - pd_scale * sv) > otg::EPS || fabs(cv - v0_scale * sv) > otg::EPS ||
+										fabs(ca - a0_scale * sv) > otg::EPS || fabs(tv - vf_scale * sv) > otg::EPS ||
+										fabs(0.0 - af_scale * sv) > otg::EPS);
+			if (!gany(off)) {
+				const double npc = control_limiting * sv / scale_limiting;
+				bool lane_ok = true;
+				if (active && j != limiting) {
+					const double t_profile = duration - p.brake.duration - 0.0;
+					UNROLL for (int i = 0; i < 7; i++) p.t[i] = plt[i];
+					p.control_signs = pl_cs;
+					if (pl_cs == otg3::UDDU)
+						lane_ok = otg3::check_tj<otg3::UDDU, otg3::L_NONE>(p, t_profile, npc, vmax, -vmax, amax, -amax, jmax);
+					else
+						lane_ok = otg3::check_tj<otg3::UDUD, otg3::L_NONE>(p, t_profile, npc, vmax, -vmax, amax, -amax, jmax);
+					p.limits = pl_lim;
+				}
+				if (!gany(!lane_ok)) return otg::WORKING;
+			}
+		}
+	}
+	// time synchronisation (calculator_target.hpp:469-529)
+	bool bad = false;
+	if (active && j != limiting) {
+		const double t_profile = duration - p.brake.duration - 0.0;
+		if (fabs(t_profile - bl.tmin) < 2 * otg::EPS) {
+			p = bl.pmin;
+		} else if (bl.a && fabs(t_profile - bl.aright) < 2 * otg::EPS) {
+			p = bl.aprof;
+		} else if (bl.b && fabs(t_profile - bl.bright) < 2 * otg::EPS) {
+			p = bl.bprof;
+		} else if (!otg3::step2(p, t_profile, vmax, -vmax, amax, -amax, jmax)) {
+			bad = true;
+		}
+	}
+	return gany(bad) ? otg::ERR_SYNCHRONIZATION : otg::WORKING;
+}
+
+// Ruckig::update (ruckig.hpp:180-216), jerk-limited
+DI int ruckig_update(LaneGen3& g, bool active, int n, double dt, double vmax, double amax, double epoch) {
+	int result = otg::WORKING;
+	g.replanned = 0;
+	const bool differs = gany(active && !(g.in_cp == g.ci_cp && g.in_cv == g.ci_cv && g.in_ca == g.ci_ca && g.in_tp == g.ci_tp &&
+										  g.in_tv == g.ci_tv)) ||
+						 g.ci_epoch != epoch || !g.ci_init;
+	if (differs) {
+		const bool invalid = active && (isnan(g.jmax) || g.jmax < 0.0 || isnan(amax) || amax < 0.0 || isnan(vmax) || vmax < 0.0 || isnan(g.in_ca) ||
+										isnan(g.in_cv) || isnan(g.in_tv) || isnan(g.in_cp) || isnan(g.in_tp) || g.in_tv > vmax || g.in_tv < -vmax);
+		if (gany(invalid)) return otg::ERR_INVALID_INPUT;
+		// (a failed calculation leaves the stored rows alone: the wrapper then zeroes the input velocity / acceleration
+		// (OTG_joints.cpp:141-149), so the next update plans again before anything is sampled)
+		otg3::Prof p = g.p;
+		double duration = g.duration;
+		result = calculate3(active, n, g.in_cp, g.in_cv, g.in_ca, g.in_tp, g.in_tv, vmax, amax, g.jmax, p, duration);
+		if (result != otg::WORKING) return result;
+		g.p = p, g.duration = duration;
+		g.replanned = 1;
+		g.ci_cp = g.in_cp, g.ci_cv = g.in_cv, g.ci_ca = g.in_ca, g.ci_tp = g.in_tp, g.ci_tv = g.in_tv;
+		g.ci_epoch = epoch;
+		g.ci_init = 1;
+		g.time = 0.0;
+	}
+	g.time += dt;
+	if (active) {
+		otg3::at_time(g.p, g.duration, g.time, g.np, g.nv, g.na);
+		g.ci_cp = g.np, g.ci_cv = g.nv, g.ci_ca = g.na;
+	}
+	if (g.time > g.duration) return otg::FINISHED;
+	return result;
+}
+
 // Ruckig::update (ruckig.hpp:180-216)
 DI int ruckig_update(LaneGen& g, bool active, int n, double dt, double vmax, double amax, double epoch) {
 	int result = otg::WORKING;
@@ -243,7 +422,7 @@ DI int ruckig_update(LaneGen& g, bool active, int n, double dt, double vmax, dou
 }
 
 // OTG_joints::setGoalPositionAndVelocity (OTG_joints.cpp:98-116)
-DI void joints_set_goal(LaneGen& g, bool active, int n, double gp, double gv) {
+template <class LG> DI void joints_set_goal(LG& g, bool active, int n, double gp, double gv) {
 	if (g.target_set && gapprox(gp, g.in_tp, 0, n, 1e-12) && gapprox(gv, g.in_tv, 0, n, 1e-12)) return;
 	g.goal_reached = 0;
 	g.target_set = 1;
@@ -251,7 +430,7 @@ DI void joints_set_goal(LaneGen& g, bool active, int n, double gp, double gv) {
 }
 
 // OTG_6dof_cartesian::setGoalPositionAndLinearVelocity (OTG_6dof_cartesian.cpp:140-149): lanes 0-2
-DI void cart_set_goal_position(LaneGen& g, double gp, double gv) {
+template <class LG> DI void cart_set_goal_position(LG& g, double gp, double gv) {
 	if ((g.target_set & 1) && gapprox(gp, g.in_tp, 0, 3, 1e-3) && gapprox(gv, g.in_tv, 0, 3, 1e-3)) return;
 	g.goal_reached = 0;
 	g.target_set |= 1;
@@ -259,7 +438,7 @@ DI void cart_set_goal_position(LaneGen& g, double gp, double gv) {
 }
 // OTG_6dof_cartesian::setGoalOrientationAndAngularVelocity (OTG_6dof_cartesian.cpp:151-185); the
 // rotation algebra is done redundantly by every lane, lanes 3-5 keep their component
-DI void cart_set_goal_orientation(LaneGen& g, const double* gR, const double* gw) {
+template <class LG> DI void cart_set_goal_orientation(LG& g, const double* gR, const double* gw) {
 	if ((g.target_set & 2) && otg::approx9(g.goal_R, gR, 9, 1e-3) && otg::approx9(g.goal_w, gw, 3, 1e-3)) return;
 	const int j = lane_j();
 	g.goal_reached = 0;
@@ -285,7 +464,7 @@ DI void cart_set_goal_orientation(LaneGen& g, const double* gR, const double* gw
 // update() of both wrappers after the goal was set (OTG_joints.cpp:118-150,
 // OTG_6dof_cartesian.cpp:187-224); for the JointTask's Finished-with-velocity branch see
 // sai2b_otg_core.hpp: joints_finish
-DI void update(LaneGen& g, bool cart, bool active, int n, double dt, double vmax, double amax, double epoch) {
+template <class LG> DI void update(LG& g, bool cart, bool active, int n, double dt, double vmax, double amax, double epoch) {
 	if (g.goal_reached) return;
 	const double pp = g.np, pv = g.nv, pa = g.na;
 	g.result = ruckig_update(g, active, n, dt, vmax, amax, epoch);
