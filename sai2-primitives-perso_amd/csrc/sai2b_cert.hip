@@ -43,21 +43,25 @@ __global__ __launch_bounds__(64) void tick_cert_kernel(const DevParams* __restri
 // getters: TemplateTask.h:42-88) through the same whitened cascade (cert::tick<.., TASK = true>): what examples 01 / 04 /
 // 18 / 19 do by hand per period. Robots whose N_prec is not a whitened projector, whose level is not certified or that
 // carry singularity history go — nothing stored — to a work list for the generic task_kernel (sai2b_kernels.hip).
-// tk_count: one counter, zeroed by the host before the launch.
+// tk_counts: two counters alternating between launches (`parity`), as behind tick_fast_kernel: this launch fills
+// [parity] and clears [1 - parity] for the next one.
 template <int MCAP>
 __global__ __launch_bounds__(64) void task_cert_kernel(const DevParams* __restrict__ Pp, int task, const double* __restrict__ Nprec_in,
 													  const double* __restrict__ tau_prec, double* __restrict__ tau_out, double* __restrict__ N_out,
-													  double* __restrict__ Ntot_out, int do_torque, int* __restrict__ tk_count,
-													  int* __restrict__ tk_list) {
-	__shared__ real pend_lds[cert::LDS_SLOTS * 64];
-	__shared__ real q0_lds[(N * (N + 1) / 2) * 64];
+													  double* __restrict__ Ntot_out, int do_torque, int* __restrict__ tk_counts,
+													  int* __restrict__ tk_list, int parity) {
+	__shared__ real pend_lds[(cert::LDS_SLOTS + cert::TASK_EXTRA) * 64];
+	static_assert((cert::LDS_SLOTS + cert::TASK_EXTRA) * 64 * 8 * 4 <= 160 * 1024 || N > 7, "four wavefronts per CU (robots of up to 7 joints)");
 	const DevParams& P = *Pp;
 	const int B = P.B;
 	const int b = blockIdx.x * 64 + threadIdx.x;
+	if (blockIdx.x == 0 && threadIdx.x == 0) ((gint*)tk_counts)[1 - parity] = 0;
+	int* tk_count = tk_counts + parity;
 	if (b >= B) return;
 	real* pend = pend_lds + threadIdx.x;
 	cert::TaskArgs io;
-	io.task = task, io.Nprec = Nprec_in, io.tau_prec = tau_prec, io.N_out = N_out, io.Ntot_out = Ntot_out, io.q0 = q0_lds + threadIdx.x;
+	io.task = task, io.Nprec = Nprec_in, io.tau_prec = tau_prec, io.N_out = N_out, io.Ntot_out = Ntot_out, io.q0 = pend;
+	io.write_active = do_torque ? 0 : 1;
 	real tau[N];
 	const bool mine = cert::tick<MCAP, cert::DM, DevModel, true>(P, P.model, B, b, tau_prec != nullptr, pend, tau, &io);
 	const unsigned long long declined = __ballot(!mine);
@@ -127,16 +131,15 @@ extern "C" int sai2b_launch_range_cert(const sai2b::DevParams* d_params, int B, 
 }
 
 extern "C" int sai2b_launch_task_cert(const sai2b::DevParams* d_params, int B, int task, int max_rows, const double* Nprec_in,
-									  const double* tau_prec, double* tau_out, double* N_out, double* Ntot_out, int do_torque, int* tk_count,
-									  int* tk_list, hipStream_t stream) {
+									  const double* tau_prec, double* tau_out, double* N_out, double* Ntot_out, int do_torque, int* tk_counts,
+									  int* tk_list, int parity, hipStream_t stream) {
 	const dim3 grid((B + 63) / 64), block(64);
-	if (hipMemsetAsync(tk_count, 0, sizeof(int), stream) != hipSuccess) return 1;
 	if (max_rows <= 3)
 		hipLaunchKernelGGL(sai2b::task_cert_kernel<3>, grid, block, 0, stream, d_params, task, Nprec_in, tau_prec, tau_out, N_out, Ntot_out,
-						   do_torque, tk_count, tk_list);
+						   do_torque, tk_counts, tk_list, parity);
 	else
 		hipLaunchKernelGGL(sai2b::task_cert_kernel<6>, grid, block, 0, stream, d_params, task, Nprec_in, tau_prec, tau_out, N_out, Ntot_out,
-						   do_torque, tk_count, tk_list);
+						   do_torque, tk_counts, tk_list, parity);
 	return (int)hipGetLastError();
 }
 

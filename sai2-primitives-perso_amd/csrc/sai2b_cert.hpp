@@ -484,8 +484,16 @@ struct TaskArgs {
 	const real* tau_prec;  // [N][B] or NULL (the no-argument computeTorques)
 	real* N_out;		   // [N * N][B] or NULL
 	real* Ntot_out;		   // [N * N][B] or NULL
-	real* q0;			   // this lane's column of an LDS area of N (N + 1) / 2 doubles (stride 64): Q before the level
+	real* q0;			   // this lane's column of the LDS area (stride 64); slot of entry k: q0_slot(k): Q before the level
+	int write_active;	   // model update of a gated JointTask: OTG_ACTIVE (does the task have a range this tick?) for otg_kernel
 };
+
+// where the N (N + 1) / 2 entries of Q0 wait in the lane's LDS column: the slots a one-task call leaves unused — the
+// gravity torques' [0, N) and what lies behind the one task's deferred stores [N + 12, PEND_SLOTS) — then TASK_EXTRA
+// slots behind the factor of the bounded inertia estimate (4 for 7 joints: four workgroups per CU still fit)
+constexpr int TASK_FREE = N + (PEND_SLOTS - N - 12);
+constexpr int TASK_EXTRA = (N * (N + 1) / 2 > TASK_FREE) ? N * (N + 1) / 2 - TASK_FREE : 0;
+DI int q0_slot(int k) { return k < N ? k : (k < TASK_FREE ? k + 12 : LDS_SLOTS + (k - TASK_FREE)); }
 
 template <int MCAP, int DCAP, class MD, bool TASK = false>
 DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, real* pend, real* tau, const TaskArgs* io = nullptr) {
@@ -569,7 +577,7 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 			task_first = wrows == 0;  // an N_prec that IS the identity
 			UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) Q[i * N + j] = Qf[i * N + j];
 		}
-		UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) io->q0[(i * (i + 1) / 2 + j) * 64] = Q[i * N + j];
+		UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) io->q0[q0_slot(i * (i + 1) / 2 + j) * 64] = Q[i * N + j];
 	}
 #pragma unroll 1
 	for (int ti = (TASK ? io->task : 0); ti < (TASK ? io->task + 1 : P.n_tasks); ti++) {
@@ -627,6 +635,12 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 			// JointTask::updateTaskModel / computeTorques (JointTask.cpp:218-356)
 			CSTAMP(30);
 			const int k0 = t.k0;
+			if constexpr (TASK) {
+				// what the generic kernel's model pass tells the generator kernels (sai2b_device.hpp: jt_task): a full
+				// JointTask has a range while N_prec leaves a direction, a certified partial one keeps all its rows (an
+				// uncertified one is decided — and this row overwritten — by the generic pass behind)
+				if (t.otg_gated && io->write_active) st(t.otg_state, OTG_ACTIVE, B, b, (!t.full_selection || first || wrows < N) ? 1.0 : 0.0);
+			}
 			real va[N], vf[N];
 			{
 				// goals and integrators first, in one burst (rows clamped into the task's own: the loads must not sit
@@ -733,7 +747,7 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 				real S[N * N];
 				UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) {
 					const real q1 = Q[i * N + j];
-					S[i * N + j] = which ? q1 : ((i == j ? 1.0 : 0.0) - io->q0[(i * (i + 1) / 2 + j) * 64] + q1);
+					S[i * N + j] = which ? q1 : ((i == j ? 1.0 : 0.0) - io->q0[q0_slot(i * (i + 1) / 2 + j) * 64] + q1);
 				}
 				UNROLL for (int j = 0; j < N; j++) {
 					real col[N];

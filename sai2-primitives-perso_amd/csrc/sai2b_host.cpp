@@ -89,8 +89,9 @@ struct sai2b_ctx {
 	double* sim_tau = nullptr;	// staging for host torques / bias read-back of the simulation harness
 	// task-level calls (TemplateTask.h:42-88): per task the caller's N_prec, the task's N and N * N_prec of the
 	// last sai2b_task_update_model, its torques and a staging copy of a host tau_prec; created on first use
-	int* tk_count = nullptr;  // work list of the task-level SVD-free kernel (task_cert_kernel): 1 counter + B robot indices
+	int* tk_count = nullptr;  // work list of the task-level SVD-free kernel (task_cert_kernel): 2 alternating counters + B robot indices
 	int* tk_list = nullptr;
+	int tk_parity = 0;
 	bool no_task_cert = false;	// SAI2B_NO_TASK_CERT=1: the generic task_kernel for every robot (A/B)
 	struct TaskIO {
 		double *Nprec = nullptr, *N = nullptr, *Ntot = nullptr, *tau = nullptr, *tau_prec = nullptr;
@@ -1251,13 +1252,14 @@ static int launch_task_call(sai2b_ctx* ctx, int task, const double* Np, const do
 	if (rows) {
 		if (!ctx->tk_count) {
 			int rc;
-			if ((rc = dev_alloc(ctx, &ctx->tk_count, 1))) return rc;
+			if ((rc = dev_alloc(ctx, &ctx->tk_count, 2))) return rc;
 			if ((rc = dev_alloc(ctx, &ctx->tk_list, (size_t)ctx->B))) return rc;
 		}
+		ctx->tk_parity ^= 1;
 		if (sai2b_launch_task_cert(ctx->d_params, ctx->B, task, rows, Np, tp, tau_out, N_out, Ntot_out, do_torque, ctx->tk_count, ctx->tk_list,
-								   ctx->stream) ||
-			sai2b_launch_task(ctx->d_params, ctx->B, task, Np, tp, tau_out, N_out, Ntot_out, commit_sh, do_torque, ctx->tk_count, ctx->tk_list,
-							  ctx->stream))
+								   ctx->tk_parity, ctx->stream) ||
+			sai2b_launch_task(ctx->d_params, ctx->B, task, Np, tp, tau_out, N_out, Ntot_out, commit_sh, do_torque, ctx->tk_count + ctx->tk_parity,
+							  ctx->tk_list, ctx->stream))
 			return set_error(ctx, SAI2B_RUNTIME_ERROR, "task launch failed");
 		ctx->launches += 2;
 		return SAI2B_OK;
@@ -1312,7 +1314,9 @@ extern "C" int sai2b_task_compute_torques(sai2b_ctx* ctx, int task, const double
 		if ((rc = copy_rows(ctx, io.tau_prec, tau_prec, N, 0))) return rc;
 		tp = io.tau_prec;
 	}
-	if ((rc = launch_task_call(ctx, task, Np, tp, io.tau, io.N, io.Ntot, io.model_fresh ? 0 : 1, 1))) return rc;
+	// (behind updateTaskModel of the same state the nullspaces are in place: only the torques are produced)
+	if ((rc = launch_task_call(ctx, task, Np, tp, io.tau, io.model_fresh ? nullptr : io.N, io.model_fresh ? nullptr : io.Ntot, io.model_fresh ? 0 : 1, 1)))
+		return rc;
 	ctx->ticks += ctx->B;
 	io.model_fresh = false;
 	ctx->q_is_pose = true;	// computeTorques caches the task's current pose

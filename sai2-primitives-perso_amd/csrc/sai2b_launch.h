@@ -28,11 +28,11 @@ extern "C" int sai2b_launch_task(const sai2b::DevParams* d_params, int B, int ta
 								 double* tau_out, double* N_out, double* Ntot_out, int commit_sh, int do_torque, const int* tk_count,
 								 const int* tk_list, hipStream_t stream);
 // the same calls through the whitened cascade (sai2b_cert.hip: task_cert_kernel); robots it declines are appended to
-// tk_list (tk_count: one counter, zeroed by this launch) for sai2b_launch_task(..., tk_count, tk_list) behind it.
-// max_rows: rows of the task (<= 3 selects the small instantiation)
+// tk_list (tk_counts: two counters, zero before the first launch, `parity` alternating between launches) for
+// sai2b_launch_task(..., tk_counts + parity, tk_list) behind it. max_rows: rows of the task (<= 3: the small instantiation)
 extern "C" int sai2b_launch_task_cert(const sai2b::DevParams* d_params, int B, int task, int max_rows, const double* Nprec_in,
-									  const double* tau_prec, double* tau_out, double* N_out, double* Ntot_out, int do_torque, int* tk_count,
-									  int* tk_list, hipStream_t stream);
+									  const double* tau_prec, double* tau_out, double* N_out, double* Ntot_out, int do_torque, int* tk_counts,
+									  int* tk_list, int parity, hipStream_t stream);
 // one kernel of a (fast) tick on its own, for per-kernel timing: part 0 = first kernel, part 1 = the
 // generic kernel over the work list of the SVD-free one. fb_counts: 2 ints, zero before the first
 // launch; fb_list: B ints; parity alternates 0/1 between consecutive launches of the SVD-free kernel

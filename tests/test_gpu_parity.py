@@ -228,6 +228,58 @@ def test_certified_generic_path_matches_oracle(name):
                 assert e[~regular].max() < 1e-6, (name, tick, e[~regular].max())
 
 
+def _level_conditioning(o, tasks, B):
+    """per robot: the worst condition number among the operational-space inertias of the hierarchy's levels — Lambda of a
+    MotionForceTask (SingularityHandler.cpp:110-134), M_partial of a JointTask (JointTask.cpp:241-245), taken over their
+    range (singular values below 1e-9 of the largest are the directions the level does not have)"""
+    kappa = np.ones(B)
+    for t, (kind, _) in enumerate(tasks):
+        A = o.get_mft_lambda(t)[0] if kind == "mft" else o.get_jt_inertia(t)[0]
+        k = int(round(np.sqrt(A.shape[0])))
+        sv = np.linalg.svd(A.reshape(k, k, B).transpose(2, 0, 1), compute_uv=False)
+        keep = sv > 1e-9 * sv[:, :1]
+        smin = np.where(keep, sv, np.inf).min(axis=1)
+        kappa = np.maximum(kappa, np.where(sv[:, 0] > 0, sv[:, 0] / smin, 1.0))
+    return kappa
+
+
+@pytest.mark.parametrize("name", ["full_mft_jt", "c4", "mft_then_overconstrained_jt"])
+def test_error_against_the_oracle_grows_with_the_conditioning_it_is_blamed_on(name):
+    """Outside BASELINE's filtered workloads (s5 / s0 >= 0.1) the asserted bound is 1e-9 .. 1e-8 instead of 1e-10, and the
+    comments blame ill-conditioned operational-space inertias. MEASURED here on 8 192 UNFILTERED random poses per
+    hierarchy: per robot kappa = the worst condition number among the inertias the levels invert (_level_conditioning);
+    two backward-stable FP64 factorisations differ by ~ eps * kappa. Asserted: relative torque error <= 16 * eps * kappa
+    for EVERY robot outside a singularity-blending region, hence 1e-10 wherever kappa <= 2.8e4. For [full
+    MotionForceTask, JointTask] kappa stays below 1e3 on any pose the non-singular branch admits (s5 / s0 >= 0.06 bounds
+    cond(J J^T) by 278): BASELINE's C2 / C3 / C5 are 1e-10 workloads with or without their pose filter. The hierarchies
+    with partial tasks are where kappa reaches 1e5 .. 1e7 (a selected joint nearly inside the range of the task above
+    it), which is what the 1e-9 / 1e-8 of the other tests correspond to."""
+    B = 8192
+    tasks = [("mft", {"partial": None}), ("jt", {"selection": None})] if name == "full_mft_jt" else HIERARCHIES[name]
+    inp = _custom_inputs(tasks, B, seed=4242)
+    eps = np.finfo(float).eps
+    o, g = _pair(inp, introspection=False)
+    ol.load_inputs(o, inp)
+    ol.load_inputs(g, inp)
+    tau_o, tau_g = o.tick(), g.tick()
+    regular = np.ones(B, dtype=bool)
+    for t, (kind, _) in enumerate(tasks):
+        if kind == "mft":
+            _, _, ns = o.get_mft_singularity(t)
+            regular &= ns == (o.tasks[t].pos_range + o.tasks[t].ori_range)
+    kappa = _level_conditioning(o, tasks, B)
+    e = _err(tau_g, tau_o)
+    ratio = e[regular] / (eps * kappa[regular])
+    print(f"{name}: regular {regular.sum()}, kappa median {np.median(kappa[regular]):.1e} 99.9 % {np.quantile(kappa[regular], 0.999):.1e} max "
+          f"{kappa[regular].max():.1e}; err max {e[regular].max():.2e}; max err / (eps kappa) {ratio.max():.3f}")
+    assert ratio.max() < 16, (name, float(ratio.max()))
+    assert e[regular & (kappa <= 2.8e4)].max() < TOL
+    if name == "full_mft_jt":
+        assert kappa[regular].max() < 1e3
+    else:
+        assert kappa[regular].max() > 1e5, "the unfiltered workload should contain the ill-conditioned robots"
+
+
 def test_fused_tick_equals_split_api_and_is_repeatable():
     inp = pkg.workloads.make_inputs(3, B=1024, seed=77)
     g = pkg.Controller(pkg.panda_model(), pkg.task_configs(inp["tasks"]), inp["B"])
