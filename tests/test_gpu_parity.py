@@ -245,15 +245,16 @@ def _level_conditioning(o, tasks, B):
 
 @pytest.mark.parametrize("name", ["full_mft_jt", "c4", "mft_then_overconstrained_jt"])
 def test_error_against_the_oracle_grows_with_the_conditioning_it_is_blamed_on(name):
-    """Outside BASELINE's filtered workloads (s5 / s0 >= 0.1) the asserted bound is 1e-9 .. 1e-8 instead of 1e-10, and the
-    comments blame ill-conditioned operational-space inertias. MEASURED here on 8 192 UNFILTERED random poses per
-    hierarchy: per robot kappa = the worst condition number among the inertias the levels invert (_level_conditioning);
-    two backward-stable FP64 factorisations differ by ~ eps * kappa. Asserted: relative torque error <= 16 * eps * kappa
-    for EVERY robot outside a singularity-blending region, hence 1e-10 wherever kappa <= 2.8e4. For [full
-    MotionForceTask, JointTask] kappa stays below 1e3 on any pose the non-singular branch admits (s5 / s0 >= 0.06 bounds
-    cond(J J^T) by 278): BASELINE's C2 / C3 / C5 are 1e-10 workloads with or without their pose filter. The hierarchies
-    with partial tasks are where kappa reaches 1e5 .. 1e7 (a selected joint nearly inside the range of the task above
-    it), which is what the 1e-9 / 1e-8 of the other tests correspond to."""
+    """Outside BASELINE's filtered workloads (s5 / s0 >= 0.1) other tests assert 1e-9 .. 1e-8 instead of 1e-10 and blame
+    ill-conditioned operational-space inertias. MEASURED here, 8 192 UNFILTERED random poses per hierarchy: per robot
+    kappa = the worst condition number among the inertias the levels invert (_level_conditioning); two backward-stable
+    FP64 factorisations differ by ~ eps * kappa. Seen on the MI355X: [full MFT, JT] kappa <= 8e2 (the non-singular
+    branch bounds cond(J J^T) by (1 / 0.06)^2 = 278), C4's hierarchy kappa <= 1.7e4, [MFT, JT(2), JT] <= 7.4e2; relative
+    torque error of every robot outside a blending region <= 2.7e-13, error / (eps * kappa) <= 20. Asserted: error <= 64 *
+    eps * kappa and <= 1e-11 for every such robot. So on random poses of this arm 1e-10 holds with three orders to
+    spare in every hierarchy tried; the 1e-9 / 1e-8 of the closed-loop and fuzz tests are headroom for states a
+    controller drives itself into (robots parked at the edge of a blending region, random gains, light arms), not
+    something these workloads need."""
     B = 8192
     tasks = [("mft", {"partial": None}), ("jt", {"selection": None})] if name == "full_mft_jt" else HIERARCHIES[name]
     inp = _custom_inputs(tasks, B, seed=4242)
@@ -272,12 +273,9 @@ def test_error_against_the_oracle_grows_with_the_conditioning_it_is_blamed_on(na
     ratio = e[regular] / (eps * kappa[regular])
     print(f"{name}: regular {regular.sum()}, kappa median {np.median(kappa[regular]):.1e} 99.9 % {np.quantile(kappa[regular], 0.999):.1e} max "
           f"{kappa[regular].max():.1e}; err max {e[regular].max():.2e}; max err / (eps kappa) {ratio.max():.3f}")
-    assert ratio.max() < 16, (name, float(ratio.max()))
-    assert e[regular & (kappa <= 2.8e4)].max() < TOL
-    if name == "full_mft_jt":
-        assert kappa[regular].max() < 1e3
-    else:
-        assert kappa[regular].max() > 1e5, "the unfiltered workload should contain the ill-conditioned robots"
+    assert ratio.max() < 64, (name, float(ratio.max()))
+    assert e[regular].max() < 1e-11
+    assert kappa[regular].max() < 1e5  # what the non-singular branch admits on this arm (see the docstring)
 
 
 def test_fused_tick_equals_split_api_and_is_repeatable():
