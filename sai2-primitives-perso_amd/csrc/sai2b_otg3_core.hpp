@@ -26,6 +26,15 @@
 #pragma once
 #include "sai2b_otg_core.hpp"
 
+// The planner's big functions are real calls on the device (not inlined): each is entered from several places (both
+// directions, both planners), and inlining every copy made the translation unit take six minutes to compile for nothing —
+// the planner runs out of scratch memory either way.
+#ifdef __HIPCC__
+#define SAI2B_HDN __host__ __device__ __attribute__((noinline))
+#else
+#define SAI2B_HDN inline
+#endif
+
 namespace sai2b {
 namespace otg3 {
 
@@ -171,7 +180,7 @@ SAI2B_HD void rsort(Roots& r) {
 }
 
 // solveCub (roots.hpp:60-149): a x^3 + b x^2 + c x + d = 0
-SAI2B_HD Roots solve_cub(double a, double b, double c, double d) {
+SAI2B_HDN Roots solve_cub(double a, double b, double c, double d) {
 	Roots roots;
 	roots.n = 0;
 	if (fabs(d) < EPS) {
@@ -277,7 +286,7 @@ SAI2B_HD int solve_resolvent(double (&x)[3], double a, double b, double c) {
 }
 
 // solveQuartMonic (roots.hpp:198-283): x^4 + a x^3 + b x^2 + c x + d = 0
-SAI2B_HD Roots solve_quart_monic(double a, double b, double c, double d) {
+SAI2B_HDN Roots solve_quart_monic(double a, double b, double c, double d) {
 	Roots roots;
 	roots.n = 0;
 	if (fabs(d) < EPS) {
@@ -516,7 +525,7 @@ SAI2B_HD bool is_blocked(const Block& b, double t) {
 	return (t < b.tmin) || (b.a && b.aleft < t && t < b.aright) || (b.b && b.bleft < t && t < b.bright);
 }
 // Block::calculate_block<6, true> (block.hpp:61-134)
-SAI2B_HD bool calculate_block(Block& bl, Prof* v, int count) {
+SAI2B_HDN bool calculate_block(Block& bl, Prof* v, int count) {
 	if (count == 1) {
 		set_min(bl, v[0]);
 		return true;
