@@ -24,7 +24,11 @@ __global__ __launch_bounds__(64) void tick_cert_kernel(const DevParams* __restri
 	if (b >= B) return;
 	real* pend = pend_lds + threadIdx.x;
 	real tau[N];
-	const bool mine = cert::tick<MCAP, cert::DM>(P, P.model, B, b, with_comp != 0, pend, tau);
+	// with_comp: bit 0 = JointTask compensation of the tasks above, bit 1 = singular MotionForceTasks go to the work list
+	// instead of through cert::singular_part (SAI2B_NO_INLANE_SINGULAR=1, the A/B switch)
+	cert::SingPend sp;
+	sp.task = -1;
+	const bool mine = cert::tick<MCAP, cert::DM>(P, P.model, B, b, (with_comp & 1) != 0, pend, tau, nullptr, (with_comp & 2) ? nullptr : &sp);
 	const unsigned long long declined = __ballot(!mine);
 	if (declined) {
 		int base = 0;
@@ -36,6 +40,7 @@ __global__ __launch_bounds__(64) void tick_cert_kernel(const DevParams* __restri
 		}
 	}
 	cert::flush(P, B, b, pend);
+	if constexpr (MCAP <= 3) cert::flush_singular(P, B, b, sp);
 	UNROLL for (int i = 0; i < N; i++) st(P.tau, i, B, b, tau[i] + pend[i * 64]);  // RobotController.cpp:70-72
 }
 

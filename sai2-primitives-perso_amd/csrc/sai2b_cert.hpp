@@ -49,8 +49,23 @@ __device__ int g_cstamp_n;
 		}                                                                 \
 		__builtin_amdgcn_sched_barrier(0);                                \
 	} while (0)
+// inside a divergent branch: the first active lane of workgroup 0 records
+#define CSTAMP_ANY(id)                                                                              \
+	do {                                                                                            \
+		__builtin_amdgcn_sched_barrier(0);                                                          \
+		if (blockIdx.x == 0 && (int)threadIdx.x == __ffsll((unsigned long long)__ballot(1)) - 1) { \
+			const int k_ = g_cstamp_n;                                                              \
+			if (k_ < 500) {                                                                         \
+				g_cstamps[2 * k_] = (unsigned long long)(id);                                       \
+				g_cstamps[2 * k_ + 1] = __builtin_readcyclecounter();                               \
+				g_cstamp_n = k_ + 1;                                                                \
+			}                                                                                       \
+		}                                                                                           \
+		__builtin_amdgcn_sched_barrier(0);                                                          \
+	} while (0)
 #else
 #define CSTAMP(id) do { } while (0)
+#define CSTAMP_ANY(id) asm volatile("; SAI2B_SING_" #id)
 #endif
 
 constexpr int DM = N - 1;		   // largest nullspace a full JointTask behind another task can see
@@ -114,6 +129,471 @@ DI bool certify_gram_lower(const real* G, real abs2, real rel2) {
 	return ok;
 }
 
+// ---- The singular branch of the SingularityHandler in whitened coordinates (round 3) --------------------------------
+// A MotionForceTask level whose certificate fails used to send the robot to the generic kernel, which redid the whole
+// tick in projector form (the "work-list pass": half of a C4 step for 5.5 % of the robots). Everything the handler does
+// inside and around a blending region (SingularityHandler.cpp:76-160, 230-295, 313-367) has a whitened form too:
+//     Jp^T = X,  X W = Xs (one-sided Jacobi: U = W, sigma_j = |Xs_j|, V_j = Xs_j / sigma_j),  Y' = L^-1 Xs = Y W
+//     non-singular columns (positions < split):  Y'_ns = Z_ns R_ns:  Lambda_ns = (R^T R)^-1,  N_ns = L^-T (I - Z_ns Z_ns^T) L^T
+//     singular columns:                          Lambda_s = (Y'_s^T Y'_s)^-1
+//     posture task  Jpost = V_s^T N_ns N_prec:   L^-1 Jpost^T = Q' L^-1 V_s =: Yp = Z_p R_p,  Q' = Q - Z_ns Z_ns^T
+//     N N_prec = L^-T (Q' - Z_p Z_p^T) L^T
+// so the level still takes `rank` directions out of Q — Z_ns and Z_p instead of the Z of Y — and the cascade below goes on
+// in whitened form. Columns are handled by flags (ns[j] / singular otherwise), never by position: no run-time register
+// indexing. What is not handled here goes to the work list as before: a fully singular task (s_0 < s_abs_tol) and
+// enforce_handling_strategy = false (they consume fewer directions than `rank`: wrows would stop being batch-uniform),
+// a second singular MotionForceTask of the same robot, 4- to 6-row tasks (MCAP = 6: the arrays do not fit).
+
+// singularity bookkeeping of the one MotionForceTask that went through the branch, kept in registers until the robot is
+// known to finish in this kernel (flush_singular)
+struct SingPend {
+	int task;  // -1: none
+	int clear, write_prior, ntypes, idx, word, count, size, c1, c2;
+	int t2mask;	 // bit 2 i: store MFT_T2DIR + i, bit 2 i + 1: the value is +1 (else -1)
+};
+struct SingArgs {
+	const DevParams* P;
+	const DevTask* t;
+	int ti, B, b, enabled;
+	real fnorm;		 // |unit_mass_force + force_related_terms| over all six coordinates (SingularityHandler.cpp:349)
+	const real* pu;	 // M columns of the basis of range(P) in the six task coordinates (6 x 6 row-major), or NULL: the leading ones
+	SingPend* sp;
+};
+
+// pose of the control frame alone (one running frame: classifySingularity's perturbed kinematics, :253-258)
+template <class MD>
+DI void pose_only(const MD& md, const DevTask& t, const real* q, real* x, real* R) {
+	real Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pp[3] = {0, 0, 0};
+	UNROLL for (int k = 0; k < 3; k++) x[k] = 0;
+	UNROLL for (int k = 0; k < 9; k++) R[k] = 0;
+	UNROLL for (int i = 0; i < N; i++) {
+		real RE[9], pi[3];
+		UNROLL for (int k = 0; k < 3; k++)
+			pi[k] = fma(Rp[3 * k], md.xyz[i][0], fma(Rp[3 * k + 1], md.xyz[i][1], fma(Rp[3 * k + 2], md.xyz[i][2], pp[k])));
+		mm<3, 3, 3>(Rp, md.E[i], RE);
+		real s, c;
+		sincos_joint(q[i], &s, &c);
+		const bool pris = md.jtype[i] != 0;
+		if (pris) s = 0, c = 1;
+		UNROLL for (int k = 0; k < 3; k++) {
+			Rp[3 * k + 0] = fma(c, RE[3 * k], s * RE[3 * k + 1]);
+			Rp[3 * k + 1] = fma(c, RE[3 * k + 1], -s * RE[3 * k]);
+			Rp[3 * k + 2] = RE[3 * k + 2];
+			if (pris) pi[k] = fma(q[i], RE[3 * k + 2], pi[k]);
+			pp[k] = pi[k];
+		}
+		if (t.link == i) {
+			UNROLL for (int k = 0; k < 3; k++)
+				x[k] = fma(Rp[3 * k], t.frame_pos[0], fma(Rp[3 * k + 1], t.frame_pos[1], fma(Rp[3 * k + 2], t.frame_pos[2], pp[k])));
+			mm<3, 3, 3>(Rp, t.frame_rot, R);
+		}
+	}
+}
+
+// Gram-Schmidt of the columns of Y flagged `on` (Z overwrites them; the others become zero columns with rinv = 0, so that
+// solves with R leave zeros in their places). Returns the smallest squared norm met (a collapsed column: caller declines).
+template <int M>
+DI real masked_gram_schmidt(real* Y, const bool* on, real* R, real* rinv) {
+	real least = 1e300;
+	UNROLL for (int j = 0; j < M; j++) {
+		real nn = 0;
+		UNROLL for (int i = 0; i < N; i++) nn = fma(Y[j * N + i], Y[j * N + i], nn);
+		least = on[j] ? fmin(least, nn) : least;
+		const real r = on[j] ? rsqrt(nn) : 0.0;
+		rinv[j] = r;
+		UNROLL for (int i = 0; i < N; i++) Y[j * N + i] = on[j] ? Y[j * N + i] * r : 0.0;
+		UNROLL for (int k = j + 1; k < M; k++) {
+			real s = 0;
+			UNROLL for (int i = 0; i < N; i++) s = fma(Y[j * N + i], Y[k * N + i], s);
+			R[j * M + k] = s;
+			UNROLL for (int i = 0; i < N; i++) Y[k * N + i] = fma(-s, Y[j * N + i], Y[k * N + i]);
+		}
+	}
+	return least;
+}
+// u = R^-T a over the flagged columns (rinv = 0 elsewhere), then w = Z u
+template <int M>
+DI void gs_apply(const real* Z, const real* R, const real* rinv, const real* a, real* w) {
+	real u[M];
+	UNROLL for (int j = 0; j < M; j++) {
+		real t = a[j];
+		UNROLL for (int i = 0; i < j; i++) t = fma(-R[i * M + j], u[i], t);
+		u[j] = t * rinv[j];
+	}
+	UNROLL for (int i = 0; i < N; i++) {
+		real s = 0;
+		UNROLL for (int c = 0; c < M; c++) s = fma(Z[c * N + i], u[c], s);
+		w[i] = s;
+	}
+}
+// (A^T A restricted to the flagged columns)^-1 a, A's columns given as A[j * N + i]; unflagged places return 0
+template <int M>
+DI void masked_gram_solve(const real* A, const bool* on, real* a) {
+	real G[M * M], LG[M * M], dG[M];
+	UNROLL for (int i = 0; i < M; i++) UNROLL for (int j = 0; j <= i; j++) {
+		real s = 0;
+		UNROLL for (int l = 0; l < N; l++) s = fma(A[i * N + l], A[j * N + l], s);
+		G[i * M + j] = (on[i] && on[j]) ? s : ((i == j) ? 1.0 : 0.0);
+	}
+	chol<M>(G, LG, dG);
+	UNROLL for (int j = 0; j < M; j++) a[j] = on[j] ? a[j] : 0.0;
+	solve_lower<M>(LG, dG, a);
+	solve_lower_t<M>(LG, dG, a);
+}
+// tau += L w
+DI void add_l_times(const real* L, const real* w, real* tau) {
+	UNROLL for (int i = 0; i < N; i++) {
+		real s = 0;
+		UNROLL for (int k = 0; k <= i; k++) s = fma(L[i * N + k], w[k], s);
+		tau[i] += s;
+	}
+}
+
+// Y, JP: what level() built (Y = L^-1 Jp^T by columns, JP = rows of Jp); fu / ff: unit mass force and force related terms in
+// the task's reduced coordinates. Adds the level's torques to tau and takes its directions out of Q. false: not handled.
+template <int M>
+DI bool singular_part(const Fact& f, const SingArgs& sa, real* Y, const real* JP, bool first, bool last, int decoupling,
+					  const real* fu, const real* ff, real* Q, real* tau) {
+	const DevParams& P = *sa.P;
+	const DevTask& t = *sa.t;
+	const int B = sa.B, b = sa.b;
+	SingPend& sp = *sa.sp;
+	if (sp.task >= 0) return false;	 // one per robot
+	CSTAMP_ANY(50);
+	// ---- thin SVD of Jp by one-sided Jacobi on Jp^T (SingularityHandler.cpp:78-81)
+	real X[N * M], W[M * M], sv[M];
+	UNROLL for (int c = 0; c < M; c++) UNROLL for (int i = 0; i < N; i++) X[i * M + c] = JP[c * N + i];
+	hestenes<N, M>(X, W);
+	CSTAMP_ANY(51);
+	int pos[M];
+	UNROLL for (int j = 0; j < M; j++) {
+		real a = 0;
+		UNROLL for (int r = 0; r < N; r++) a = fma(X[r * M + j], X[r * M + j], a);
+		sv[j] = sqrt(a);
+	}
+	real s0 = 0;
+	UNROLL for (int j = 0; j < M; j++) {
+		int p = 0;
+		UNROLL for (int k = 0; k < M; k++) p += (sv[k] > sv[j] || (sv[k] == sv[j] && k < j)) ? 1 : 0;
+		pos[j] = p;
+		s0 = fmax(s0, sv[j]);
+	}
+	// ---- range split (:83-143)
+	int split = M;
+	real alpha = 1;
+	{
+		bool found = false;
+		UNROLL for (int i = 1; i < M; i++) {
+			real si = 0;
+			UNROLL for (int j = 0; j < M; j++) si = (pos[j] == i) ? sv[j] : si;
+			const real icn = si / s0;
+			if (!found && icn < t.s_max) {
+				alpha = fmin(fmax((icn - t.s_min) / (t.s_max - t.s_min), 0.0), 1.0);
+				split = i;
+				found = true;
+			}
+		}
+	}
+	if (s0 < t.s_abs_tol || (split < M && !t.enforce)) return false;
+	bool ns[M], sg[M];
+	UNROLL for (int j = 0; j < M; j++) ns[j] = pos[j] < split, sg[j] = !ns[j];
+	const bool bie = decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES, impedance = decoupling == SAI2B_IMPEDANCE;
+	// forces in the rotated coordinates: U^T F
+	real au[M], af[M];
+	UNROLL for (int j = 0; j < M; j++) {
+		real a = 0, c = 0;
+		UNROLL for (int r = 0; r < M; r++) {
+			a = fma(W[r * M + j], fu[r], a);
+			c = fma(W[r * M + j], ff[r], c);
+		}
+		au[j] = a, af[j] = c;
+	}
+	// Y' = Y W (Y is dead afterwards: overwritten)
+	{
+		real Yp[M * N];
+		UNROLL for (int j = 0; j < M; j++) UNROLL for (int i = 0; i < N; i++) {
+			real s = 0;
+			UNROLL for (int c = 0; c < M; c++) s = fma(Y[c * N + i], W[c * M + j], s);
+			Yp[j * N + i] = s;
+		}
+		UNROLL for (int i = 0; i < M * N; i++) Y[i] = Yp[i];
+	}
+	CSTAMP_ANY(52);
+	// ---- bounded inertia: YB = LB^-1 Xs (all columns), for Lambda_ns_modified and Lambda_s_modified (:184-206)
+	real zs[M];	 // Lambda_s_modified U_s^T Fu
+	real zn[M];	 // Lambda_ns_modified U_ns^T Fu when it is not Lambda_ns (bounded inertia), through the direct term
+	UNROLL for (int j = 0; j < M; j++) zs[j] = au[j], zn[j] = 0;
+	if (bie) {
+		real LB[N * N], dB[N], YB[M * N];
+		load_lb(f.lb, LB, dB);
+		UNROLL for (int j = 0; j < M; j++) {
+			UNROLL for (int i = 0; i < N; i++) YB[j * N + i] = X[i * M + j];
+			solve_lower<N>(LB, dB, YB + j * N);
+		}
+		UNROLL for (int j = 0; j < M; j++) zn[j] = au[j];
+		masked_gram_solve<M>(YB, ns, zn);
+		masked_gram_solve<M>(YB, sg, zs);
+	} else {
+		masked_gram_solve<M>(Y, sg, zs);  // Lambda_s = (Jp_s M^-1 Jp_s^T)^-1 (:121)
+	}
+	CSTAMP_ANY(53);
+	// ---- singular-direction torques, sanitised and clamped (:354-365); 0 when nothing is singular
+	real tau_s[N];
+	UNROLL for (int i = 0; i < N; i++) {
+		real s = 0;
+		UNROLL for (int j = 0; j < M; j++) s = fma(X[i * M + j], sg[j] ? zs[j] + af[j] : 0.0, s);
+		s = (s != s) ? 0.0 : fmin(fmax(s, -P.model.effort[i]), P.model.effort[i]);
+		tau_s[i] = s;
+	}
+	// ---- non-singular torques (:321-322 = :307-309): direct terms through Xs, the Lambda_ns term through Z_ns
+	{
+		UNROLL for (int i = 0; i < N; i++) {
+			real s = 0;
+			UNROLL for (int j = 0; j < M; j++) s = fma(X[i * M + j], ns[j] ? af[j] + (impedance ? au[j] : zn[j]) : 0.0, s);
+			tau[i] += s;
+		}
+	}
+	real R[M * M], rinv[M];
+	real least = masked_gram_schmidt<M>(Y, ns, R, rinv);
+	if (!bie && !impedance) {
+		real a[M], w[N];
+		UNROLL for (int j = 0; j < M; j++) a[j] = ns[j] ? au[j] : 0.0;
+		gs_apply<M>(Y, R, rinv, a, w);
+		add_l_times(f.L, w, tau);
+	}
+	// Q' = Q - Z_ns Z_ns^T
+	UNROLL for (int c = 0; c < M; c++)
+		UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) Q[i * N + j] = fma(-Y[c * N + i], Y[c * N + j], Q[i * N + j]);
+	CSTAMP_ANY(54);
+	// ---- bookkeeping (classifySingularity, :230-295)
+	const int prev_types = ldi(t.istate, IS_NTYPES, B, b);
+	sp.task = sa.ti;
+	sp.clear = sp.write_prior = sp.t2mask = 0;
+	sp.ntypes = sp.idx = sp.word = sp.count = sp.size = sp.c1 = sp.c2 = 0;
+	if (split == M) {  // the SVD says: not singular after all (the certificate is conservative)
+		sp.clear = prev_types != 0;
+		if (!sp.clear) sp.task = -1;
+		return least > 1e-280;
+	}
+	// the state the bookkeeping and the joint strategy need, in one burst
+	int c1 = ldi(t.istate, IS_C1, B, b), c2 = ldi(t.istate, IS_C2, B, b);
+	const int ring_count = ldi(t.istate, IS_COUNT, B, b), ring_size = ldi(t.istate, IS_SIZE, B, b);
+	real q[N], dq[N], qprior[N], t2dir[N];
+	UNROLL for (int i = 0; i < N; i++) {
+		q[i] = ld(P.q, i, B, b);
+		dq[i] = ld(P.dq, i, B, b);
+		qprior[i] = ld(t.state, MFT_QPRIOR + i, B, b);
+		t2dir[i] = ld(t.state, MFT_T2DIR + i, B, b);
+	}
+	const int ring_word = ldi(t.istate, (ring_count % t.sh_cap) >> 5, B, b);
+	sp.write_prior = (prev_types == 0 || c2 > c1);
+	UNROLL for (int i = 0; i < N; i++) qprior[i] = sp.write_prior ? q[i] : qprior[i];
+	// V_s = Xs_j / sigma_j with the sign convention shared with the oracle (largest-magnitude component positive)
+	real vscale[M];
+	UNROLL for (int j = 0; j < M; j++) {
+		real big = 0, bigabs = -1;
+		UNROLL for (int i = 0; i < N; i++) {
+			const bool take = fabs(X[i * M + j]) > bigabs;
+			bigabs = take ? fabs(X[i * M + j]) : bigabs;
+			big = take ? X[i * M + j] : big;
+		}
+		const real inv = sv[j] > 0 ? 1.0 / sv[j] : 0.0;
+		vscale[j] = sg[j] ? (big < 0 ? -inv : inv) : 0.0;
+	}
+	bool any1 = false;
+	real us0[M], vs0[N];
+	UNROLL for (int r = 0; r < M; r++) us0[r] = 0;
+	UNROLL for (int i = 0; i < N; i++) vs0[i] = 0;
+	{
+		// (the pose at q is recomputed rather than kept from the Jacobian sweep: keeping its 12 numbers alive through the
+		// level measured 3 us slower, scripts/micro/cert_variants.sh)
+		real x0[3], R0[9];
+		pose_only(P.model, t, q, x0, R0);
+		const int pass0 = t.sv_sign == SAI2B_SV_SIGN_V_MAX_NEGATIVE ? 1 : 0;
+		const int pass1 = t.sv_sign == SAI2B_SV_SIGN_V_MAX_POSITIVE ? 0 : 1;
+#pragma unroll 1
+		for (int p = split; p < M; p++) {
+			real u6[6], v[N], w[M];
+			UNROLL for (int r = 0; r < M; r++) w[r] = 0;
+			UNROLL for (int i = 0; i < N; i++) v[i] = 0;
+			UNROLL for (int j = 0; j < M; j++)
+				if (pos[j] == p) {
+					const real sgn = vscale[j] < 0 ? -1.0 : 1.0;
+					UNROLL for (int r = 0; r < M; r++) w[r] = sgn * W[r * M + j];
+					UNROLL for (int i = 0; i < N; i++) v[i] = vscale[j] * X[i * M + j];
+				}
+			if (p == split) {
+				UNROLL for (int r = 0; r < M; r++) us0[r] = w[r];
+				UNROLL for (int i = 0; i < N; i++) vs0[i] = v[i];
+			}
+			UNROLL for (int k = 0; k < 6; k++) {
+				real s = 0;
+				if (sa.pu) {
+					UNROLL for (int r = 0; r < M; r++) s = fma(sa.pu[k * 6 + r], w[r], s);
+				} else {
+					UNROLL for (int r = 0; r < M; r++) s = (k == r) ? w[r] : s;
+				}
+				u6[k] = s;
+			}
+			bool moved[2] = {false, false};
+#pragma unroll 1
+			for (int pass = pass0; pass <= pass1; pass++) {
+				const real step = pass ? -t.perturb : t.perturb;
+				real qp[N], x1[3], R1[9], d[6];
+				UNROLL for (int i = 0; i < N; i++) qp[i] = fma(step, v[i], q[i]);
+				pose_only(P.model, t, qp, x1, R1);
+				UNROLL for (int k = 0; k < 3; k++) d[k] = x1[k] - x0[k];
+				orientation_error(R1, R0, d + 3);
+				real m = 0;
+				UNROLL for (int k = 0; k < 6; k++) m = fma(d[k], u6[k], m);
+				if (pass)
+					moved[1] = fabs(m) > t.type_1_tol;
+				else
+					moved[0] = fabs(m) > t.type_1_tol;
+			}
+			const bool type1 = t.sv_sign == SAI2B_SV_SIGN_BOTH ? (moved[0] && moved[1]) : (moved[0] || moved[1]);
+			any1 = any1 || type1;
+		}
+	}
+	CSTAMP_ANY(55);
+	{  // history ring (:276-293), stored by flush_singular
+		int count = ring_count, size = ring_size;
+		const int cap = t.sh_cap;
+		const int idx = count % cap;
+		int word = ring_word;
+		const int bit = 1 << (idx & 31);
+		if (size == cap) {
+			if (word & bit)
+				c1--;
+			else
+				c2--;
+		} else {
+			size++;
+		}
+		if (any1) {
+			word |= bit;
+			c1++;
+		} else {
+			word &= ~bit;
+			c2++;
+		}
+		sp.idx = idx >> 5, sp.word = word, sp.count = (count + 1) % (cap * 32768), sp.size = size, sp.c1 = c1, sp.c2 = c2, sp.ntypes = M - split;
+	}
+	CSTAMP_ANY(56);
+	// ---- posture task in the singular joint directions (:152-157): Yp = Q' L^-1 V_s
+	real Yp[M * N];
+	UNROLL for (int j = 0; j < M; j++) {
+		real col[N], y[N];
+		UNROLL for (int i = 0; i < N; i++) col[i] = vscale[j] * X[i * M + j];
+		solve_lower<N>(f.L, f.dL, col);
+		UNROLL for (int i = 0; i < N; i++) {
+			real s = 0;
+			UNROLL for (int k = 0; k < N; k++) s = fma(symat(Q, i, k), col[k], s);
+			y[i] = s;
+		}
+		UNROLL for (int i = 0; i < N; i++) Yp[j * N + i] = y[i];
+	}
+	CSTAMP_ANY(57);
+	if (!impedance) {
+		// joint strategy (:327-351): unit torques through Lambda_joint_s_modified, the open-loop type-2 torques directly
+		real hl[M], hd[M];	// V_s^T (what goes through Lambda_joint_s_modified), V_s^T (what goes in directly)
+		UNROLL for (int j = 0; j < M; j++) hd[j] = 0;
+		real ut[N];
+		if (c1 > c2 || t.enforce_t1) {
+			UNROLL for (int i = 0; i < N; i++) ut[i] = -t.kp1 * (q[i] - qprior[i]) - t.kv1 * dq[i];
+		} else {
+			real fTd = 0;
+			const real finv = sa.fnorm > 0 ? 1.0 / sa.fnorm : 1.0;	// normalized() of a zero vector is the vector
+			UNROLL for (int r = 0; r < M; r++) fTd = fma((fu[r] + ff[r]) * finv, us0[r], fTd);
+			real um[N];
+			UNROLL for (int i = 0; i < N; i++) {
+				real dir = t2dir[i];
+				if (vs0[i] != 0) {
+					if (fabs(q[i] - P.model.q_upper[i]) < t.t2_angle) {
+						dir = -1;
+						sp.t2mask |= 1 << (2 * i);
+					} else if (fabs(q[i] - P.model.q_lower[i]) < t.t2_angle) {
+						dir = 1;
+						sp.t2mask |= 3 << (2 * i);
+					}
+				}
+				um[i] = dir * fabs(fTd) * t.t2_ratio * P.model.effort[i];
+				ut[i] = -t.kv2 * dq[i];
+			}
+			UNROLL for (int j = 0; j < M; j++) {
+				real s = 0;
+				UNROLL for (int i = 0; i < N; i++) s = fma(vscale[j] * X[i * M + j], um[i], s);
+				hd[j] = s;
+			}
+		}
+		UNROLL for (int j = 0; j < M; j++) {
+			real s = 0;
+			UNROLL for (int i = 0; i < N; i++) s = fma(vscale[j] * X[i * M + j], ut[i], s);
+			hl[j] = s;
+		}
+		if (bie) {	// Lambda_joint_s_modified = (Jpost M_BIE^-1 Jpost^T)^-1, Jpost^T = L Yp (:202-205)
+			real LB[N * N], dB[N], YB[M * N];
+			load_lb(f.lb, LB, dB);
+			UNROLL for (int j = 0; j < M; j++) {
+				UNROLL for (int i = 0; i < N; i++) {
+					real s = 0;
+					UNROLL for (int k = 0; k <= i; k++) s = fma(f.L[i * N + k], Yp[j * N + k], s);
+					YB[j * N + i] = s;
+				}
+				solve_lower<N>(LB, dB, YB + j * N);
+			}
+			masked_gram_solve<M>(YB, sg, hl);
+		} else {
+			masked_gram_solve<M>(Yp, sg, hl);
+		}
+		real w[N], tj[N];
+		UNROLL for (int i = 0; i < N; i++) {
+			real s = 0;
+			UNROLL for (int j = 0; j < M; j++) s = fma(Yp[j * N + i], sg[j] ? hl[j] + hd[j] : 0.0, s);
+			w[i] = s;
+			tj[i] = 0;
+		}
+		add_l_times(f.L, w, tj);
+		UNROLL for (int i = 0; i < N; i++) tau[i] += alpha * tau_s[i] + (1 - alpha) * tj[i];  // :366
+	}
+	CSTAMP_ANY(58);
+	// N = N_posture N_ns: Q'' = Q' - Z_p Z_p^T
+	least = fmin(least, masked_gram_schmidt<M>(Yp, sg, R, rinv));
+	UNROLL for (int c = 0; c < M; c++)
+		UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) Q[i * N + j] = fma(-Yp[c * N + i], Yp[c * N + j], Q[i * N + j]);
+	CSTAMP_ANY(59);
+	return least > 1e-280;
+}
+
+// the deferred bookkeeping of singular_part, for a robot that finishes in this kernel
+DI void flush_singular(const DevParams& P, int B, int b, const SingPend& sp) {
+	if (sp.task < 0) return;
+	const DevTask& t = P.task[sp.task];
+	int* IS = t.istate;
+	if (sp.clear) {	 // leaving the singular region (:239-245)
+		sti(IS, IS_NTYPES, B, b, 0);
+		sti(IS, IS_COUNT, B, b, 0);
+		sti(IS, IS_SIZE, B, b, 0);
+		sti(IS, IS_C1, B, b, 0);
+		sti(IS, IS_C2, B, b, 0);
+		return;
+	}
+	if (sp.write_prior) {  // entering conditions (:233-236)
+		for (int i = 0; i < N; i++) {
+			st(t.state, MFT_QPRIOR + i, B, b, ld(P.q, i, B, b));
+			st(t.state, MFT_DQPRIOR + i, B, b, ld(P.dq, i, B, b));
+		}
+	}
+	for (int i = 0; i < N; i++)
+		if (sp.t2mask & (1 << (2 * i))) st(t.state, MFT_T2DIR + i, B, b, (sp.t2mask & (2 << (2 * i))) ? 1.0 : -1.0);
+	sti(IS, sp.idx, B, b, sp.word);
+	sti(IS, IS_COUNT, B, b, sp.count);
+	sti(IS, IS_SIZE, B, b, sp.size);
+	sti(IS, IS_C1, B, b, sp.c1);
+	sti(IS, IS_C2, B, b, sp.c2);
+	sti(IS, IS_NTYPES, B, b, sp.ntypes);
+}
+
 // One level of the cascade in reduced coordinates, M rows exactly (an instantiation per task size: the arrays of
 // a 3-row task are 3 columns wide, nothing is guarded). Jr: the task's rows (Jr[c * N + i]).
 // Task forces: Lambda va + Lambda_mod vf + vd with Lambda_mod by the decoupling type (SingularityHandler.cpp:
@@ -123,9 +603,10 @@ DI bool certify_gram_lower(const real* G, real abs2, real rel2) {
 // bounded-inertia ones: Jp^T x = LB (YB x), YB = LB^-1 Jp^T overwrites Jp) -> Gram-Schmidt of Y ->
 // Lambda term as L (Z R^-T a) -> downdate of Q.
 // TORQUE = false: the cascade alone (certificate and Q), for the range pass ahead of the trajectory generators.
-template <int M, bool TORQUE = true>
+// SING: a level whose certificate fails goes through singular_part (MotionForceTasks of the small instantiation).
+template <int M, bool TORQUE = true, bool SING = false>
 DI bool level(const Fact& f, const real* Jr, bool first, bool last, bool do_cert, real abs2, real rel2, int decoupling,
-			  bool has_va, const real* va, const real* vf, const real* vd, real* Q, real* tau) {
+			  bool has_va, const real* va, const real* vf, const real* vd, real* Q, real* tau, const SingArgs* sa = nullptr) {
 	real Y[M * N], JP[M * N];
 	UNROLL for (int c = 0; c < M; c++) {
 		real col[N];
@@ -160,6 +641,9 @@ DI bool level(const Fact& f, const real* Jr, bool first, bool last, bool do_cert
 			G[i * M + j] = s;
 		}
 		ok = certify_gram_lower<M>(G, abs2, rel2);
+	}
+	if constexpr (SING && TORQUE && M >= 2) {	 // (a one-row task has no blending region: it is regular or fully singular)
+		if (sa->enabled && !ok) return singular_part<M>(f, *sa, Y, JP, first, last, decoupling, vf, vd, Q, tau);
 	}
 	SAI2B_PHASE();
 	CSTAMP(21);
@@ -250,13 +734,13 @@ DI bool level(const Fact& f, const real* Jr, bool first, bool last, bool do_cert
 	return ok;
 }
 // run-time row count (the same for every robot) -> the instantiation
-template <int M, bool TORQUE = true>
+template <int M, bool TORQUE = true, bool SING = false>
 DI bool level_any(int m, const Fact& f, const real* Jr, bool first, bool last, bool do_cert, real abs2, real rel2, int decoupling,
-				  bool has_va, const real* va, const real* vf, const real* vd, real* Q, real* tau) {
+				  bool has_va, const real* va, const real* vf, const real* vd, real* Q, real* tau, const SingArgs* sa = nullptr) {
 	if constexpr (M > 1) {
-		if (m < M) return level_any<M - 1, TORQUE>(m, f, Jr, first, last, do_cert, abs2, rel2, decoupling, has_va, va, vf, vd, Q, tau);
+		if (m < M) return level_any<M - 1, TORQUE, SING>(m, f, Jr, first, last, do_cert, abs2, rel2, decoupling, has_va, va, vf, vd, Q, tau, sa);
 	}
-	return level<M, TORQUE>(f, Jr, first, last, do_cert, abs2, rel2, decoupling, has_va, va, vf, vd, Q, tau);
+	return level<M, TORQUE, SING>(f, Jr, first, last, do_cert, abs2, rel2, decoupling, has_va, va, vf, vd, Q, tau, sa);
 }
 
 // A full JointTask behind other tasks: Jp = N_prec = L^-T Q L^T with rank D = n - (rows of the certified tasks
@@ -495,8 +979,11 @@ constexpr int TASK_FREE = N + (PEND_SLOTS - N - 12);
 constexpr int TASK_EXTRA = (N * (N + 1) / 2 > TASK_FREE) ? N * (N + 1) / 2 - TASK_FREE : 0;
 DI int q0_slot(int k) { return k < N ? k : (k < TASK_FREE ? k + 12 : LDS_SLOTS + (k - TASK_FREE)); }
 
+// sp: the bookkeeping of a MotionForceTask that went through singular_part (the caller flushes it with the rest);
+// NULL: such robots go to the work list (MCAP = 6, the task-level calls, SAI2B_NO_INLANE_SINGULAR)
 template <int MCAP, int DCAP, class MD, bool TASK = false>
-DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, real* pend, real* tau, const TaskArgs* io = nullptr) {
+DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, real* pend, real* tau, const TaskArgs* io = nullptr,
+			 SingPend* sp = nullptr) {
 	CSTAMP(0);
 	Fact f;
 	bool ok = true;
@@ -587,7 +1074,10 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 			// MotionForceTask::updateTaskModel / computeTorques (MotionForceTask.cpp:247-509) in the fully
 			// non-singular branch of the SingularityHandler (SingularityHandler.cpp:100-141,307-309)
 			CSTAMP(10);
-			ok = ok && (ldi(t.istate, IS_NTYPES, B, b) == 0);
+			constexpr bool SING = !TASK && MCAP <= 3;
+			const bool inlane = SING && sp != nullptr;
+			const int prev_types = ldi(t.istate, IS_NTYPES, B, b);
+			if (!inlane) ok = ok && (prev_types == 0);
 			real Jw[6 * N], Fu[6], Ff[6];
 			{
 				real q[N], sc[2 * N], x[3], R[9];
@@ -619,17 +1109,36 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 			if (wrows + m > N) ok = false;	// more task rows than joints left: never full rank
 			const real abs2 = t.s_abs_tol * t.s_abs_tol, rel2 = t.s_max * t.s_max;
 			const real zero[6] = {0, 0, 0, 0, 0, 0};
+			SingArgs sa;
+			SingPend none;
+			none.task = 0;	// "taken": singular_part declines
+			sa.P = &P, sa.t = &t, sa.ti = ti, sa.B = B, sa.b = b, sa.enabled = inlane, sa.pu = nullptr, sa.sp = inlane ? sp : &none;
+			const int task_before = sa.sp->task;
+			{
+				real nn = 0;
+				UNROLL for (int i = 0; i < 6; i++) nn = fma(Fu[i] + Ff[i], Fu[i] + Ff[i], nn);
+				sa.fnorm = sqrt(nn);
+			}
 			bool c_ok;
 			if (t.full_projection || t.p_lead < 6) {  // range(P) = the leading coordinates: rows and forces as they are
-				c_ok = level_any<(MCAP < 6 ? MCAP : 6)>(m, f, Jw, first, last, true, abs2, rel2, t.decoupling, false, zero, Fu, Ff, Q, tau);
+				c_ok = level_any<(MCAP < 6 ? MCAP : 6), true, SING>(m, f, Jw, first, last, true, abs2, rel2, t.decoupling, false, zero, Fu, Ff, Q, tau, &sa);
 			} else {  // rows PU^T J, forces PU^T F
 				real Jr[6 * N], fu[6], ff[6];
 				mm_tn<6, 6, N>(t.PU, Jw, Jr);
 				mv_t<6, 6>(t.PU, Fu, fu);
 				mv_t<6, 6>(t.PU, Ff, ff);
-				c_ok = level_any<(MCAP < 6 ? MCAP : 6)>(m, f, Jr, first, last, true, abs2, rel2, t.decoupling, false, zero, fu, ff, Q, tau);
+				sa.pu = t.PU;
+				c_ok = level_any<(MCAP < 6 ? MCAP : 6), true, SING>(m, f, Jr, first, last, true, abs2, rel2, t.decoupling, false, zero, fu, ff, Q, tau, &sa);
 			}
 			ok = ok && c_ok;
+			if (inlane && prev_types != 0 && sp->task == task_before) {
+				// certified, with singularity history: the robot has left the region and the history goes (:239-245)
+				if (sp->task >= 0) {
+					ok = false;
+				} else {
+					sp->task = ti, sp->clear = 1;
+				}
+			}
 			wrows += m;
 		} else {
 			// JointTask::updateTaskModel / computeTorques (JointTask.cpp:218-356)

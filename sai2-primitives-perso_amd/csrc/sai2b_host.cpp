@@ -38,6 +38,7 @@ struct sai2b_ctx {
 	bool no_fast_path = false;	// SAI2B_NO_FAST_PATH=1 in the environment: always run the generic kernel
 	bool blocking_sync = false;	// SAI2B_BLOCKING_SYNC=1: sai2b_synchronize() blocks without polling first
 	bool no_cert_path = false;	// SAI2B_NO_CERT_PATH=1: no SVD-free kernel for general hierarchies (sai2b_cert.hpp)
+	bool no_inlane_singular = false;  // SAI2B_NO_INLANE_SINGULAR=1: singular MotionForceTasks of tick_cert_kernel<3> go to the work list
 	bool prefer_cert = false;	// SAI2B_PREFER_CERT=1 (diagnostic): sai2b_cert.hpp also where sai2b_fast.hpp applies
 	// lanes per robot of the generic kernel: SAI2B_GENERIC_LANES = 16 / 8 / 1 (1: the one-lane-per-robot kernel),
 	// default 0 = by the amount of work (generic_lanes())
@@ -660,6 +661,8 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	ctx->no_cert_path = nc && nc[0] == '1';
 	const char* ntc = std::getenv("SAI2B_NO_TASK_CERT");
 	ctx->no_task_cert = ntc && ntc[0] == '1';
+	const char* nis = std::getenv("SAI2B_NO_INLANE_SINGULAR");
+	ctx->no_inlane_singular = nis && nis[0] == '1';
 	const char* pc = std::getenv("SAI2B_PREFER_CERT");
 	ctx->prefer_cert = pc && pc[0] == '1';
 	if (const char* gl = std::getenv("SAI2B_GENERIC_LANES")) ctx->generic_lanes_env = std::atoi(gl);
@@ -1136,7 +1139,7 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 	if (fast_launch) ctx->fb_parity ^= 1;
 	// a long work list (thousands of robots) is throughput, not latency: two robots per DPP row, as for a whole batch
 	const bool long_list = fast_launch && fast >= 3 && ctx->fb_last_seen > 4096;  // (16 lanes: 4 robots x 1024 wavefronts in one round)
-	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast_now, ctx->baked_model ? 1 : 0, commit_sh, with_comp, do_torque, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, !fast_launch || long_list), ctx->stream))
+	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast_now, ctx->baked_model ? 1 : 0, commit_sh, (with_comp ? 1 : 0) | (ctx->no_inlane_singular ? 2 : 0), do_torque, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, !fast_launch || long_list), ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
 	ctx->launches++;
 	if (fast_launch && fast >= 3 && !ctx->fb_seen_pending && (ctx->cert_probe++ & 7) == 0) {

@@ -311,14 +311,16 @@ static void launch_fast(int fast, int baked, dim3 grid, dim3 block, hipStream_t 
 #endif
 }
 
+// with_comp: bit 0 = JointTask compensation, bit 1 (tick_cert_kernel only) = no in-lane singular handling
 extern "C" int sai2b_launch_tick(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int commit_sh,
-								 int with_comp, int do_torque, int* fb_counts, int* fb_list, int parity, int group, hipStream_t stream) {
+								 int with_comp_bits, int do_torque, int* fb_counts, int* fb_list, int parity, int group, hipStream_t stream) {
 	const dim3 grid((B + 63) / 64), block(64);
+	const int with_comp = with_comp_bits & 1;
 	// the fast path produces torques only: introspection and model-only passes use the generic kernel
 	if (debug) {
 		hipLaunchKernelGGL((sai2b::tick_kernel<true>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, nullptr, nullptr);
 	} else if (fast != 0 && do_torque && commit_sh) {
-		launch_fast(fast, baked, grid, block, stream, d_params, with_comp, fb_counts, fb_list, parity);
+		launch_fast(fast, baked, grid, block, stream, d_params, fast >= 3 ? with_comp_bits : with_comp, fb_counts, fb_list, parity);
 		if (group)
 			return sai2b_launch_tick_group(d_params, B, group, 0, commit_sh, with_comp, do_torque, (const int*)(fb_counts + parity),
 										   (const int*)fb_list, stream);
