@@ -16,7 +16,7 @@ namespace sai2b {
 template <int MCAP>
 __global__ __launch_bounds__(64) void tick_cert_kernel(const DevParams* __restrict__ Pp, int with_comp, int* __restrict__ fb_counts,
 													  int* __restrict__ fb_list, int parity) {
-	__shared__ real pend_lds[cert::LDS_SLOTS * 64];
+	__shared__ real pend_lds[(cert::LDS_SLOTS + (MCAP <= 3 ? cert::POSE_SLOTS : 0)) * 64];
 	const DevParams& P = *Pp;
 	const int B = P.B;
 	const int b = blockIdx.x * 64 + threadIdx.x;

@@ -73,6 +73,12 @@ constexpr int PEND_SLOTS = 36;	   // deferred stores per robot: gravity N, Motio
 constexpr int LB_SLOTS = N * (N + 1) / 2 + N;  // factor of the bounded inertia estimate, parked in LDS between its uses
 constexpr int LDS_SLOTS = PEND_SLOTS + LB_SLOTS;  // doubles per lane: 4 workgroups of 64 lanes fit the 160 KB of a CU
 static_assert(LDS_SLOTS * 64 * 8 * 4 <= 160 * 1024, "four wavefronts per CU");
+// what is left of a lane's column (7 joints: 9 doubles) holds the control frame's pose for the in-lane singular branch
+#ifdef SAI2B_SING_NO_LDS_POSE  // A/B (scripts/micro/cert_variants.sh)
+constexpr int POSE_SLOTS = 0;
+#else
+constexpr int POSE_SLOTS = ((LDS_SLOTS + 9) * 64 * 8 * 4 <= 160 * 1024) ? 9 : 0;
+#endif
 
 struct Fact {
 	real L[N * N], dL[N];	// M = L L^T (lower), reciprocal diagonal
@@ -157,6 +163,7 @@ struct SingArgs {
 	int ti, B, b, enabled;
 	real fnorm;		 // |unit_mass_force + force_related_terms| over all six coordinates (SingularityHandler.cpp:349)
 	const real* pu;	 // M columns of the basis of range(P) in the six task coordinates (6 x 6 row-major), or NULL: the leading ones
+	const real* pose;  // this lane's LDS column behind the bounded-inertia factor (POSE_SLOTS doubles, stride 64), see singular_part
 	SingPend* sp;
 };
 
@@ -240,6 +247,21 @@ DI void masked_gram_solve(const real* A, const bool* on, real* a) {
 	solve_lower<M>(LG, dG, a);
 	solve_lower_t<M>(LG, dG, a);
 }
+// A <- LB^-1 A for the M columns of A (A[j * N + i]): the factor of the bounded inertia estimate comes from LDS a row at a
+// time (each row serves all the columns) and is never whole in registers
+template <int M>
+DI void solve_lb_columns(const real* lb, real* A) {
+	UNROLL for (int i = 0; i < N; i++) {
+		real row[N];
+		UNROLL for (int k = 0; k < i; k++) row[k] = lb[(i * (i + 1) / 2 + k) * 64];
+		const real di = lb[(N * (N + 1) / 2 + i) * 64];
+		UNROLL for (int c = 0; c < M; c++) {
+			real t = A[c * N + i];
+			UNROLL for (int k = 0; k < i; k++) t = fma(-row[k], A[c * N + k], t);
+			A[c * N + i] = t * di;
+		}
+	}
+}
 // tau += L w
 DI void add_l_times(const real* L, const real* w, real* tau) {
 	UNROLL for (int i = 0; i < N; i++) {
@@ -251,9 +273,16 @@ DI void add_l_times(const real* L, const real* w, real* tau) {
 
 // Y, JP: what level() built (Y = L^-1 Jp^T by columns, JP = rows of Jp); fu / ff: unit mass force and force related terms in
 // the task's reduced coordinates. Adds the level's torques to tau and takes its directions out of Q. false: not handled.
+//
+// ONE singular direction (split = M - 1: every one of the 3 611 robots inside a blending region of the C4 workload), or none
+// after all (the certificate is sufficient, not necessary); two or more small singular values of a 2- or 3-row task go to the
+// work list. The columns are brought into the order [the M - 1 larger singular values | the smallest]: everything about
+// the regular block is then compile-time shaped like a level of M - 1 rows, the singular direction is one vector and its
+// Lambdas are scalars, and one flag (`reg`: the last column is regular too) is all that is left of the column masks.
 template <int M>
 DI bool singular_part(const Fact& f, const SingArgs& sa, real* Y, const real* JP, bool first, bool last, int decoupling,
 					  const real* fu, const real* ff, real* Q, real* tau) {
+	constexpr int K = M - 1;
 	const DevParams& P = *sa.P;
 	const DevTask& t = *sa.t;
 	const int B = sa.B, b = sa.b;
@@ -261,199 +290,193 @@ DI bool singular_part(const Fact& f, const SingArgs& sa, real* Y, const real* JP
 	if (sp.task >= 0) return false;	 // one per robot
 	CSTAMP_ANY(50);
 	// ---- thin SVD of Jp by one-sided Jacobi on Jp^T (SingularityHandler.cpp:78-81)
-	real X[N * M], W[M * M], sv[M];
+	real X[N * M], W[M * M];
 	UNROLL for (int c = 0; c < M; c++) UNROLL for (int i = 0; i < N; i++) X[i * M + c] = JP[c * N + i];
 	hestenes<N, M>(X, W);
 	CSTAMP_ANY(51);
-	int pos[M];
+	real sv[M];
 	UNROLL for (int j = 0; j < M; j++) {
 		real a = 0;
 		UNROLL for (int r = 0; r < N; r++) a = fma(X[r * M + j], X[r * M + j], a);
 		sv[j] = sqrt(a);
 	}
-	real s0 = 0;
+	// positions in descending order (ties by index, as the oracle sorts); js: the column of the smallest singular value
+	real s0 = 0, s_last = 0, s_prev = 0;
+	int js = 0;
 	UNROLL for (int j = 0; j < M; j++) {
 		int p = 0;
 		UNROLL for (int k = 0; k < M; k++) p += (sv[k] > sv[j] || (sv[k] == sv[j] && k < j)) ? 1 : 0;
-		pos[j] = p;
 		s0 = fmax(s0, sv[j]);
+		js = (p == M - 1) ? j : js;
+		s_last = (p == M - 1) ? sv[j] : s_last;
+		s_prev = (p == M - 2) ? sv[j] : s_prev;	 // (M = 2: position 0, the largest)
 	}
-	// ---- range split (:83-143)
-	int split = M;
-	real alpha = 1;
+	// ---- range split (:83-143): the first position i >= 1 with s_i / s_0 < s_max
+	if (s0 < t.s_abs_tol) return false;			   // fully singular: the task is passed through
+	if (M > 2 && s_prev / s0 < t.s_max) return false;  // two or more singular directions
+	const real icn = s_last / s0;
+	const bool reg = !(icn < t.s_max);	// not singular after all
+	const real alpha = reg ? 1.0 : fmin(fmax((icn - t.s_min) / (t.s_max - t.s_min), 0.0), 1.0);
+	if (!reg && !t.enforce) return false;
+	const bool bie = decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES, impedance = decoupling == SAI2B_IMPEDANCE;
+	// ---- columns in the order [regular block | js]: Xs (= Jp^T U), Y' = Y U, U^T F
+	real Xc[M * N], Yc[M * N], au[M], af[M], ws[M];
 	{
-		bool found = false;
-		UNROLL for (int i = 1; i < M; i++) {
-			real si = 0;
-			UNROLL for (int j = 0; j < M; j++) si = (pos[j] == i) ? sv[j] : si;
-			const real icn = si / s0;
-			if (!found && icn < t.s_max) {
-				alpha = fmin(fmax((icn - t.s_min) / (t.s_max - t.s_min), 0.0), 1.0);
-				split = i;
-				found = true;
+		real Ur[M * M];	 // Ur[r * M + k]: component r of column k in the new order
+		UNROLL for (int k = 0; k < K; k++) UNROLL for (int r = 0; r < M; r++) Ur[r * M + k] = (js <= k) ? W[r * M + k + 1] : W[r * M + k];
+		UNROLL for (int r = 0; r < M; r++) {  // the last column: column js, by selects
+			real v = 0;
+			UNROLL for (int j = 0; j < M; j++) v = (js == j) ? W[r * M + j] : v;
+			Ur[r * M + K] = v;
+			ws[r] = v;
+		}
+		UNROLL for (int k = 0; k < M; k++) {
+			UNROLL for (int i = 0; i < N; i++) {
+				real v;
+				if (k < K) {
+					v = (js <= k) ? X[i * M + (k + 1 < M ? k + 1 : k)] : X[i * M + k];	// (k + 1 < M always holds here)
+				} else {
+					v = 0;
+					UNROLL for (int j = 0; j < M; j++) v = (js == j) ? X[i * M + j] : v;
+				}
+				Xc[k * N + i] = v;
+			}
+			real a = 0, c = 0;
+			UNROLL for (int r = 0; r < M; r++) {
+				a = fma(Ur[r * M + k], fu[r], a);
+				c = fma(Ur[r * M + k], ff[r], c);
+			}
+			au[k] = a, af[k] = c;
+			UNROLL for (int i = 0; i < N; i++) {
+				real y = 0;
+				UNROLL for (int r = 0; r < M; r++) y = fma(Y[r * N + i], Ur[r * M + k], y);
+				Yc[k * N + i] = y;
 			}
 		}
 	}
-	if (s0 < t.s_abs_tol || (split < M && !t.enforce)) return false;
-	bool ns[M], sg[M];
-	UNROLL for (int j = 0; j < M; j++) ns[j] = pos[j] < split, sg[j] = !ns[j];
-	const bool bie = decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES, impedance = decoupling == SAI2B_IMPEDANCE;
-	// forces in the rotated coordinates: U^T F
-	real au[M], af[M];
-	UNROLL for (int j = 0; j < M; j++) {
-		real a = 0, c = 0;
-		UNROLL for (int r = 0; r < M; r++) {
-			a = fma(W[r * M + j], fu[r], a);
-			c = fma(W[r * M + j], ff[r], c);
-		}
-		au[j] = a, af[j] = c;
-	}
-	// Y' = Y W (Y is dead afterwards: overwritten)
-	{
-		real Yp[M * N];
-		UNROLL for (int j = 0; j < M; j++) UNROLL for (int i = 0; i < N; i++) {
-			real s = 0;
-			UNROLL for (int c = 0; c < M; c++) s = fma(Y[c * N + i], W[c * M + j], s);
-			Yp[j * N + i] = s;
-		}
-		UNROLL for (int i = 0; i < M * N; i++) Y[i] = Yp[i];
-	}
 	CSTAMP_ANY(52);
-	// ---- bounded inertia: YB = LB^-1 Xs (all columns), for Lambda_ns_modified and Lambda_s_modified (:184-206)
-	real zs[M];	 // Lambda_s_modified U_s^T Fu
-	real zn[M];	 // Lambda_ns_modified U_ns^T Fu when it is not Lambda_ns (bounded inertia), through the direct term
-	UNROLL for (int j = 0; j < M; j++) zs[j] = au[j], zn[j] = 0;
+	bool on[M];
+	UNROLL for (int k = 0; k < M; k++) on[k] = (k < K) ? true : reg;
+	// ---- Lambda_s_modified U_s^T Fu (scalar) and, with bounded inertia, Lambda_ns_modified U_ns^T Fu (:184-206)
+	real zs = 0, zn[M];
+	UNROLL for (int k = 0; k < M; k++) zn[k] = 0;
 	if (bie) {
-		real LB[N * N], dB[N], YB[M * N];
-		load_lb(f.lb, LB, dB);
-		UNROLL for (int j = 0; j < M; j++) {
-			UNROLL for (int i = 0; i < N; i++) YB[j * N + i] = X[i * M + j];
-			solve_lower<N>(LB, dB, YB + j * N);
-		}
-		UNROLL for (int j = 0; j < M; j++) zn[j] = au[j];
-		masked_gram_solve<M>(YB, ns, zn);
-		masked_gram_solve<M>(YB, sg, zs);
+		real YB[M * N];
+		UNROLL for (int i = 0; i < M * N; i++) YB[i] = Xc[i];
+		solve_lb_columns<M>(f.lb, YB);
+		UNROLL for (int k = 0; k < M; k++) zn[k] = au[k];
+		masked_gram_solve<M>(YB, on, zn);
+		real g = 0;
+		UNROLL for (int i = 0; i < N; i++) g = fma(YB[K * N + i], YB[K * N + i], g);
+		zs = au[K] / g;
 	} else {
-		masked_gram_solve<M>(Y, sg, zs);  // Lambda_s = (Jp_s M^-1 Jp_s^T)^-1 (:121)
+		real g = 0;
+		UNROLL for (int i = 0; i < N; i++) g = fma(Yc[K * N + i], Yc[K * N + i], g);
+		zs = au[K] / g;	 // Lambda_s = (Jp_s M^-1 Jp_s^T)^-1 (:121)
 	}
 	CSTAMP_ANY(53);
-	// ---- singular-direction torques, sanitised and clamped (:354-365); 0 when nothing is singular
+	// ---- singular-direction torques, sanitised and clamped (:354-365)
 	real tau_s[N];
 	UNROLL for (int i = 0; i < N; i++) {
-		real s = 0;
-		UNROLL for (int j = 0; j < M; j++) s = fma(X[i * M + j], sg[j] ? zs[j] + af[j] : 0.0, s);
+		real s = Xc[K * N + i] * (zs + af[K]);
 		s = (s != s) ? 0.0 : fmin(fmax(s, -P.model.effort[i]), P.model.effort[i]);
-		tau_s[i] = s;
+		tau_s[i] = reg ? 0.0 : s;
 	}
 	// ---- non-singular torques (:321-322 = :307-309): direct terms through Xs, the Lambda_ns term through Z_ns
-	{
-		UNROLL for (int i = 0; i < N; i++) {
-			real s = 0;
-			UNROLL for (int j = 0; j < M; j++) s = fma(X[i * M + j], ns[j] ? af[j] + (impedance ? au[j] : zn[j]) : 0.0, s);
-			tau[i] += s;
-		}
+	UNROLL for (int i = 0; i < N; i++) {
+		real s = 0;
+		UNROLL for (int k = 0; k < M; k++) s = fma(Xc[k * N + i], on[k] ? af[k] + (impedance ? au[k] : zn[k]) : 0.0, s);
+		tau[i] += s;
 	}
 	real R[M * M], rinv[M];
-	real least = masked_gram_schmidt<M>(Y, ns, R, rinv);
+	real least = masked_gram_schmidt<M>(Yc, on, R, rinv);
 	if (!bie && !impedance) {
 		real a[M], w[N];
-		UNROLL for (int j = 0; j < M; j++) a[j] = ns[j] ? au[j] : 0.0;
-		gs_apply<M>(Y, R, rinv, a, w);
+		UNROLL for (int k = 0; k < M; k++) a[k] = on[k] ? au[k] : 0.0;
+		gs_apply<M>(Yc, R, rinv, a, w);
 		add_l_times(f.L, w, tau);
 	}
 	// Q' = Q - Z_ns Z_ns^T
 	UNROLL for (int c = 0; c < M; c++)
-		UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) Q[i * N + j] = fma(-Y[c * N + i], Y[c * N + j], Q[i * N + j]);
+		UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) Q[i * N + j] = fma(-Yc[c * N + i], Yc[c * N + j], Q[i * N + j]);
 	CSTAMP_ANY(54);
 	// ---- bookkeeping (classifySingularity, :230-295)
 	const int prev_types = ldi(t.istate, IS_NTYPES, B, b);
 	sp.task = sa.ti;
 	sp.clear = sp.write_prior = sp.t2mask = 0;
 	sp.ntypes = sp.idx = sp.word = sp.count = sp.size = sp.c1 = sp.c2 = 0;
-	if (split == M) {  // the SVD says: not singular after all (the certificate is conservative)
+	if (reg) {	// the SVD says: not singular after all
 		sp.clear = prev_types != 0;
 		if (!sp.clear) sp.task = -1;
 		return least > 1e-280;
 	}
-	// the state the bookkeeping and the joint strategy need, in one burst
 	int c1 = ldi(t.istate, IS_C1, B, b), c2 = ldi(t.istate, IS_C2, B, b);
 	const int ring_count = ldi(t.istate, IS_COUNT, B, b), ring_size = ldi(t.istate, IS_SIZE, B, b);
-	real q[N], dq[N], qprior[N], t2dir[N];
-	UNROLL for (int i = 0; i < N; i++) {
-		q[i] = ld(P.q, i, B, b);
-		dq[i] = ld(P.dq, i, B, b);
-		qprior[i] = ld(t.state, MFT_QPRIOR + i, B, b);
-		t2dir[i] = ld(t.state, MFT_T2DIR + i, B, b);
-	}
+	real q[N];
+	UNROLL for (int i = 0; i < N; i++) q[i] = ld(P.q, i, B, b);
 	const int ring_word = ldi(t.istate, (ring_count % t.sh_cap) >> 5, B, b);
 	sp.write_prior = (prev_types == 0 || c2 > c1);
-	UNROLL for (int i = 0; i < N; i++) qprior[i] = sp.write_prior ? q[i] : qprior[i];
-	// V_s = Xs_j / sigma_j with the sign convention shared with the oracle (largest-magnitude component positive)
-	real vscale[M];
-	UNROLL for (int j = 0; j < M; j++) {
+	// V_s = Xs / sigma with the sign convention shared with the oracle (largest-magnitude component positive)
+	real v[N], us[M];
+	{
 		real big = 0, bigabs = -1;
 		UNROLL for (int i = 0; i < N; i++) {
-			const bool take = fabs(X[i * M + j]) > bigabs;
-			bigabs = take ? fabs(X[i * M + j]) : bigabs;
-			big = take ? X[i * M + j] : big;
+			const bool take = fabs(Xc[K * N + i]) > bigabs;
+			bigabs = take ? fabs(Xc[K * N + i]) : bigabs;
+			big = take ? Xc[K * N + i] : big;
 		}
-		const real inv = sv[j] > 0 ? 1.0 / sv[j] : 0.0;
-		vscale[j] = sg[j] ? (big < 0 ? -inv : inv) : 0.0;
+		const real inv = s_last > 0 ? 1.0 / s_last : 0.0;
+		const real vs = big < 0 ? -inv : inv, sgn = big < 0 ? -1.0 : 1.0;
+		UNROLL for (int i = 0; i < N; i++) v[i] = vs * Xc[K * N + i];
+		UNROLL for (int r = 0; r < M; r++) us[r] = sgn * ws[r];
 	}
-	bool any1 = false;
-	real us0[M], vs0[N];
-	UNROLL for (int r = 0; r < M; r++) us0[r] = 0;
-	UNROLL for (int i = 0; i < N; i++) vs0[i] = 0;
+	bool any1;
 	{
-		// (the pose at q is recomputed rather than kept from the Jacobian sweep: keeping its 12 numbers alive through the
-		// level measured 3 us slower, scripts/micro/cert_variants.sh)
+		// the pose at q: parked in LDS by the Jacobian sweep where the lane's column has room for it (position and two
+		// columns of the rotation), recomputed otherwise
 		real x0[3], R0[9];
-		pose_only(P.model, t, q, x0, R0);
+		if (POSE_SLOTS == 9 && t.frame_rigid) {
+			UNROLL for (int k = 0; k < 3; k++) {
+				x0[k] = sa.pose[k * 64];
+				R0[3 * k] = sa.pose[(3 + k) * 64];
+				R0[3 * k + 1] = sa.pose[(6 + k) * 64];
+			}
+			R0[2] = R0[3] * R0[7] - R0[6] * R0[4];
+			R0[5] = R0[6] * R0[1] - R0[0] * R0[7];
+			R0[8] = R0[0] * R0[4] - R0[3] * R0[1];
+		} else {
+			pose_only(P.model, t, q, x0, R0);
+		}
+		real u6[6];
+		UNROLL for (int k = 0; k < 6; k++) {
+			real s = 0;
+			if (sa.pu) {
+				UNROLL for (int r = 0; r < M; r++) s = fma(sa.pu[k * 6 + r], us[r], s);
+			} else {
+				UNROLL for (int r = 0; r < M; r++) s = (k == r) ? us[r] : s;
+			}
+			u6[k] = s;
+		}
+		// classification by FK perturbation (:253-273) along +v, -v or both (enum sai2b_singular_vector_sign)
 		const int pass0 = t.sv_sign == SAI2B_SV_SIGN_V_MAX_NEGATIVE ? 1 : 0;
 		const int pass1 = t.sv_sign == SAI2B_SV_SIGN_V_MAX_POSITIVE ? 0 : 1;
+		bool moved[2] = {false, false};
 #pragma unroll 1
-		for (int p = split; p < M; p++) {
-			real u6[6], v[N], w[M];
-			UNROLL for (int r = 0; r < M; r++) w[r] = 0;
-			UNROLL for (int i = 0; i < N; i++) v[i] = 0;
-			UNROLL for (int j = 0; j < M; j++)
-				if (pos[j] == p) {
-					const real sgn = vscale[j] < 0 ? -1.0 : 1.0;
-					UNROLL for (int r = 0; r < M; r++) w[r] = sgn * W[r * M + j];
-					UNROLL for (int i = 0; i < N; i++) v[i] = vscale[j] * X[i * M + j];
-				}
-			if (p == split) {
-				UNROLL for (int r = 0; r < M; r++) us0[r] = w[r];
-				UNROLL for (int i = 0; i < N; i++) vs0[i] = v[i];
-			}
-			UNROLL for (int k = 0; k < 6; k++) {
-				real s = 0;
-				if (sa.pu) {
-					UNROLL for (int r = 0; r < M; r++) s = fma(sa.pu[k * 6 + r], w[r], s);
-				} else {
-					UNROLL for (int r = 0; r < M; r++) s = (k == r) ? w[r] : s;
-				}
-				u6[k] = s;
-			}
-			bool moved[2] = {false, false};
-#pragma unroll 1
-			for (int pass = pass0; pass <= pass1; pass++) {
-				const real step = pass ? -t.perturb : t.perturb;
-				real qp[N], x1[3], R1[9], d[6];
-				UNROLL for (int i = 0; i < N; i++) qp[i] = fma(step, v[i], q[i]);
-				pose_only(P.model, t, qp, x1, R1);
-				UNROLL for (int k = 0; k < 3; k++) d[k] = x1[k] - x0[k];
-				orientation_error(R1, R0, d + 3);
-				real m = 0;
-				UNROLL for (int k = 0; k < 6; k++) m = fma(d[k], u6[k], m);
-				if (pass)
-					moved[1] = fabs(m) > t.type_1_tol;
-				else
-					moved[0] = fabs(m) > t.type_1_tol;
-			}
-			const bool type1 = t.sv_sign == SAI2B_SV_SIGN_BOTH ? (moved[0] && moved[1]) : (moved[0] || moved[1]);
-			any1 = any1 || type1;
+		for (int pass = pass0; pass <= pass1; pass++) {
+			const real step = pass ? -t.perturb : t.perturb;
+			real qp[N], x1[3], R1[9], d[6];
+			UNROLL for (int i = 0; i < N; i++) qp[i] = fma(step, v[i], q[i]);
+			pose_only(P.model, t, qp, x1, R1);
+			UNROLL for (int k = 0; k < 3; k++) d[k] = x1[k] - x0[k];
+			orientation_error(R1, R0, d + 3);
+			real m = 0;
+			UNROLL for (int k = 0; k < 6; k++) m = fma(d[k], u6[k], m);
+			if (pass)
+				moved[1] = fabs(m) > t.type_1_tol;
+			else
+				moved[0] = fabs(m) > t.type_1_tol;
 		}
+		any1 = t.sv_sign == SAI2B_SV_SIGN_BOTH ? (moved[0] && moved[1]) : (moved[0] || moved[1]);
 	}
 	CSTAMP_ANY(55);
 	{  // history ring (:276-293), stored by flush_singular
@@ -477,92 +500,78 @@ DI bool singular_part(const Fact& f, const SingArgs& sa, real* Y, const real* JP
 			word &= ~bit;
 			c2++;
 		}
-		sp.idx = idx >> 5, sp.word = word, sp.count = (count + 1) % (cap * 32768), sp.size = size, sp.c1 = c1, sp.c2 = c2, sp.ntypes = M - split;
+		sp.idx = idx >> 5, sp.word = word, sp.count = (count + 1) % (cap * 32768), sp.size = size, sp.c1 = c1, sp.c2 = c2, sp.ntypes = 1;
 	}
 	CSTAMP_ANY(56);
-	// ---- posture task in the singular joint directions (:152-157): Yp = Q' L^-1 V_s
-	real Yp[M * N];
-	UNROLL for (int j = 0; j < M; j++) {
-		real col[N], y[N];
-		UNROLL for (int i = 0; i < N; i++) col[i] = vscale[j] * X[i * M + j];
+	// ---- posture task in the singular joint direction (:152-157): yp = Q' L^-1 v, and the joint strategy (:327-351)
+	real yp[N];
+	{
+		real col[N];
+		UNROLL for (int i = 0; i < N; i++) col[i] = v[i];
 		solve_lower<N>(f.L, f.dL, col);
 		UNROLL for (int i = 0; i < N; i++) {
 			real s = 0;
 			UNROLL for (int k = 0; k < N; k++) s = fma(symat(Q, i, k), col[k], s);
-			y[i] = s;
+			yp[i] = s;
 		}
-		UNROLL for (int i = 0; i < N; i++) Yp[j * N + i] = y[i];
 	}
+	real npp = 0;
+	UNROLL for (int i = 0; i < N; i++) npp = fma(yp[i], yp[i], npp);
 	CSTAMP_ANY(57);
 	if (!impedance) {
-		// joint strategy (:327-351): unit torques through Lambda_joint_s_modified, the open-loop type-2 torques directly
-		real hl[M], hd[M];	// V_s^T (what goes through Lambda_joint_s_modified), V_s^T (what goes in directly)
-		UNROLL for (int j = 0; j < M; j++) hd[j] = 0;
-		real ut[N];
-		if (c1 > c2 || t.enforce_t1) {
-			UNROLL for (int i = 0; i < N; i++) ut[i] = -t.kp1 * (q[i] - qprior[i]) - t.kv1 * dq[i];
-		} else {
+		// V_s^T of the unit torques: what goes through Lambda_joint_s_modified (hl) and what goes in directly (hd); both
+		// strategies without branches
+		real hl = 0, hd = 0;
+		{
+			const bool type1 = c1 > c2 || t.enforce_t1;	 // joint holding to the entering conditions, else open-loop torques
 			real fTd = 0;
 			const real finv = sa.fnorm > 0 ? 1.0 / sa.fnorm : 1.0;	// normalized() of a zero vector is the vector
-			UNROLL for (int r = 0; r < M; r++) fTd = fma((fu[r] + ff[r]) * finv, us0[r], fTd);
-			real um[N];
+			UNROLL for (int r = 0; r < M; r++) fTd = fma((fu[r] + ff[r]) * finv, us[r], fTd);
+			const real mag = fabs(fTd) * t.t2_ratio;
+			int mask = 0;
 			UNROLL for (int i = 0; i < N; i++) {
-				real dir = t2dir[i];
-				if (vs0[i] != 0) {
-					if (fabs(q[i] - P.model.q_upper[i]) < t.t2_angle) {
-						dir = -1;
-						sp.t2mask |= 1 << (2 * i);
-					} else if (fabs(q[i] - P.model.q_lower[i]) < t.t2_angle) {
-						dir = 1;
-						sp.t2mask |= 3 << (2 * i);
-					}
-				}
-				um[i] = dir * fabs(fTd) * t.t2_ratio * P.model.effort[i];
-				ut[i] = -t.kv2 * dq[i];
+				const real dqi = ld(P.dq, i, B, b);
+				const real qpi = sp.write_prior ? q[i] : ld(t.state, MFT_QPRIOR + i, B, b);
+				const real t2i = ld(t.state, MFT_T2DIR + i, B, b);
+				const bool has = v[i] != 0;
+				const bool up = has && fabs(q[i] - P.model.q_upper[i]) < t.t2_angle;
+				const bool lo = has && !up && fabs(q[i] - P.model.q_lower[i]) < t.t2_angle;
+				const real dir = up ? -1.0 : (lo ? 1.0 : t2i);
+				mask |= (up ? 1 : (lo ? 3 : 0)) << (2 * i);
+				const real um = type1 ? 0.0 : dir * mag * P.model.effort[i];
+				const real ut = type1 ? -t.kp1 * (q[i] - qpi) - t.kv1 * dqi : -t.kv2 * dqi;
+				hl = fma(v[i], ut, hl);
+				hd = fma(v[i], um, hd);
 			}
-			UNROLL for (int j = 0; j < M; j++) {
+			sp.t2mask = type1 ? 0 : mask;
+		}
+		real lam = 1.0 / npp;  // Lambda_joint_s
+		if (bie) {			   // Lambda_joint_s_modified = (Jpost M_BIE^-1 Jpost^T)^-1, Jpost^T = L yp (:202-205)
+			real yb[N];
+			UNROLL for (int i = 0; i < N; i++) {
 				real s = 0;
-				UNROLL for (int i = 0; i < N; i++) s = fma(vscale[j] * X[i * M + j], um[i], s);
-				hd[j] = s;
+				UNROLL for (int k = 0; k <= i; k++) s = fma(f.L[i * N + k], yp[k], s);
+				yb[i] = s;
 			}
+			solve_lb_columns<1>(f.lb, yb);
+			real g = 0;
+			UNROLL for (int i = 0; i < N; i++) g = fma(yb[i], yb[i], g);
+			lam = 1.0 / g;
 		}
-		UNROLL for (int j = 0; j < M; j++) {
-			real s = 0;
-			UNROLL for (int i = 0; i < N; i++) s = fma(vscale[j] * X[i * M + j], ut[i], s);
-			hl[j] = s;
-		}
-		if (bie) {	// Lambda_joint_s_modified = (Jpost M_BIE^-1 Jpost^T)^-1, Jpost^T = L Yp (:202-205)
-			real LB[N * N], dB[N], YB[M * N];
-			load_lb(f.lb, LB, dB);
-			UNROLL for (int j = 0; j < M; j++) {
-				UNROLL for (int i = 0; i < N; i++) {
-					real s = 0;
-					UNROLL for (int k = 0; k <= i; k++) s = fma(f.L[i * N + k], Yp[j * N + k], s);
-					YB[j * N + i] = s;
-				}
-				solve_lower<N>(LB, dB, YB + j * N);
-			}
-			masked_gram_solve<M>(YB, sg, hl);
-		} else {
-			masked_gram_solve<M>(Yp, sg, hl);
-		}
+		const real coef = fma(lam, hl, hd);
 		real w[N], tj[N];
-		UNROLL for (int i = 0; i < N; i++) {
-			real s = 0;
-			UNROLL for (int j = 0; j < M; j++) s = fma(Yp[j * N + i], sg[j] ? hl[j] + hd[j] : 0.0, s);
-			w[i] = s;
-			tj[i] = 0;
-		}
+		UNROLL for (int i = 0; i < N; i++) w[i] = yp[i] * coef, tj[i] = 0;
 		add_l_times(f.L, w, tj);
 		UNROLL for (int i = 0; i < N; i++) tau[i] += alpha * tau_s[i] + (1 - alpha) * tj[i];  // :366
 	}
 	CSTAMP_ANY(58);
-	// N = N_posture N_ns: Q'' = Q' - Z_p Z_p^T
-	least = fmin(least, masked_gram_schmidt<M>(Yp, sg, R, rinv));
-	UNROLL for (int c = 0; c < M; c++)
-		UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) Q[i * N + j] = fma(-Yp[c * N + i], Yp[c * N + j], Q[i * N + j]);
+	// N = N_posture N_ns: Q'' = Q' - z_p z_p^T
+	{
+		const real r2 = 1.0 / npp;
+		UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) Q[i * N + j] = fma(-yp[i] * r2, yp[j], Q[i * N + j]);
+	}
 	CSTAMP_ANY(59);
-	return least > 1e-280;
+	return least > 1e-280 && npp > 1e-280;
 }
 
 // the deferred bookkeeping of singular_part, for a robot that finishes in this kernel
@@ -1103,6 +1112,13 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 				SAI2B_PHASE();
 				CSTAMP(13);
 				jacobian_and_pose(md, t, q, sc, Jw, x, R);
+				if constexpr (!TASK && MCAP <= 3 && POSE_SLOTS == 9) {
+					UNROLL for (int k = 0; k < 3; k++) {
+						pend[(LDS_SLOTS + k) * 64] = x[k];
+						pend[(LDS_SLOTS + 3 + k) * 64] = R[3 * k];
+						pend[(LDS_SLOTS + 6 + k) * 64] = R[3 * k + 1];
+					}
+				}
 				CSTAMP(14);
 			}
 			const int m = t.rank;
@@ -1112,7 +1128,7 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 			SingArgs sa;
 			SingPend none;
 			none.task = 0;	// "taken": singular_part declines
-			sa.P = &P, sa.t = &t, sa.ti = ti, sa.B = B, sa.b = b, sa.enabled = inlane, sa.pu = nullptr, sa.sp = inlane ? sp : &none;
+			sa.P = &P, sa.t = &t, sa.ti = ti, sa.B = B, sa.b = b, sa.enabled = inlane, sa.pu = nullptr, sa.sp = inlane ? sp : &none, sa.pose = pend + LDS_SLOTS * 64;
 			const int task_before = sa.sp->task;
 			{
 				real nn = 0;

@@ -494,6 +494,21 @@ static void fill_dev_task(const sai2b_task_config& c, DevTask& d) {
 	d.link = c.link;
 	std::memcpy(d.frame_pos, c.frame_pos, sizeof(d.frame_pos));
 	std::memcpy(d.frame_rot, c.frame_rot, sizeof(d.frame_rot));
+	{
+		// is the compliant frame's linear part a rotation (orthonormal, det +1)? Then a pose of the control frame is its
+		// position and two columns of its orientation (cert::singular_part keeps it that way); anything else the
+		// reference would accept too, and it is carried as the nine numbers it is
+		const double* R = c.frame_rot;
+		double worst = 0;
+		for (int i = 0; i < 3; i++)
+			for (int j = 0; j < 3; j++) {
+				double g = 0;
+				for (int k = 0; k < 3; k++) g += R[3 * k + i] * R[3 * k + j];
+				worst = std::fmax(worst, std::fabs(g - (i == j ? 1.0 : 0.0)));
+			}
+		const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
+		d.frame_rigid = (worst < 1e-12 && det > 0) ? 1 : 0;
+	}
 	std::memcpy(d.P, c.partial_projection, sizeof(d.P));
 	bool pid = true;
 	for (int i = 0; i < 36; i++)

@@ -45,6 +45,7 @@ struct DevTask {
 	// MotionForceTask
 	int link;
 	double frame_pos[3], frame_rot[9];
+	int frame_rigid;  // frame_rot is a rotation matrix to 1e-12 (host: fill_dev_task)
 	int full_projection; // P == I
 	int plain_motion;	 // full task, world frame, no force/moment space, no velocity saturation
 	double P[36];
