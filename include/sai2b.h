@@ -465,9 +465,10 @@ int sai2b_profile_tick(sai2b_ctx* ctx, int steps, double* first_kernel_ms, doubl
  * over the GPUs of a node creates one context each for (Sai2PrimitivesBatched.h: ShardedRobotController) */
 int sai2b_device_count(void);
 
-/* How many robots of the last tick the SVD-free kernel handed to the generic (Jacobi-SVD) kernel: those
- * inside or leaving a singularity-blending region (SingularityHandler.cpp:66-160). 0 for hierarchies
- * that run the generic kernel for every robot. Waits for the ctx stream. */
+/* How many robots of the last tick — or of the last task-level call (sai2b_task_update_model / _compute_torques), whichever
+ * came last — the SVD-free kernel handed to the generic (Jacobi-SVD) kernel: robots inside or leaving a
+ * singularity-blending region (SingularityHandler.cpp:66-160) that the SVD-free kernel does not handle itself, levels it
+ * cannot certify. The whole batch when the generic kernel ran alone. Waits for the ctx stream. */
 int sai2b_get_fallback_count(sai2b_ctx* ctx, int* robots);
 
 /* number of kernel launches and robots processed since creation (bench bookkeeping) */

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(64) void tick_cert_kernel(const DevParams* __restri
 	// with_comp: bit 0 = JointTask compensation of the tasks above, bit 1 = singular MotionForceTasks go to the work list
 	// instead of through cert::singular_part (SAI2B_NO_INLANE_SINGULAR=1, the A/B switch)
 	cert::SingPend sp;
-	sp.task = -1;
+	sp.task = -1, sp.commit = 1, sp.store_t2 = 1;
 	const bool mine = cert::tick<MCAP, cert::DM>(P, P.model, B, b, (with_comp & 1) != 0, pend, tau, nullptr, (with_comp & 2) ? nullptr : &sp);
 	const unsigned long long declined = __ballot(!mine);
 	if (declined) {
@@ -53,8 +53,12 @@ __global__ __launch_bounds__(64) void tick_cert_kernel(const DevParams* __restri
 template <int MCAP>
 __global__ __launch_bounds__(64) void task_cert_kernel(const DevParams* __restrict__ Pp, int task, const double* __restrict__ Nprec_in,
 													  const double* __restrict__ tau_prec, double* __restrict__ tau_out, double* __restrict__ N_out,
-													  double* __restrict__ Ntot_out, int do_torque, int* __restrict__ tk_counts,
+													  double* __restrict__ Ntot_out, int call_bits, int* __restrict__ tk_counts,
 													  int* __restrict__ tk_list, int parity) {
+	// call_bits: bit 0 = torques (computeTorques), bit 1 = the call commits the once-per-model-update singularity bookkeeping
+	// (updateTaskModel, or a computeTorques that has to update the model itself), bit 2 = singular MotionForceTasks go to the
+	// work list (SAI2B_NO_INLANE_SINGULAR)
+	const int do_torque = call_bits & 1;
 	__shared__ real pend_lds[(cert::LDS_SLOTS + cert::TASK_EXTRA) * 64];
 	static_assert((cert::LDS_SLOTS + cert::TASK_EXTRA) * 64 * 8 * 4 <= 160 * 1024 || N > 7, "four wavefronts per CU (robots of up to 7 joints)");
 	const DevParams& P = *Pp;
@@ -68,7 +72,9 @@ __global__ __launch_bounds__(64) void task_cert_kernel(const DevParams* __restri
 	io.task = task, io.Nprec = Nprec_in, io.tau_prec = tau_prec, io.N_out = N_out, io.Ntot_out = Ntot_out, io.q0 = pend;
 	io.write_active = do_torque ? 0 : 1;
 	real tau[N];
-	const bool mine = cert::tick<MCAP, cert::DM, DevModel, true>(P, P.model, B, b, tau_prec != nullptr, pend, tau, &io);
+	cert::SingPend sp;
+	sp.task = -1, sp.commit = (call_bits >> 1) & 1, sp.store_t2 = do_torque;
+	const bool mine = cert::tick<MCAP, cert::DM, DevModel, true>(P, P.model, B, b, tau_prec != nullptr, pend, tau, &io, (call_bits & 4) ? nullptr : &sp);
 	const unsigned long long declined = __ballot(!mine);
 	if (declined) {
 		int base = 0;
@@ -79,6 +85,7 @@ __global__ __launch_bounds__(64) void task_cert_kernel(const DevParams* __restri
 			return;
 		}
 	}
+	if constexpr (MCAP <= 3) cert::flush_singular(P, B, b, sp);
 	if (do_torque) {
 		cert::flush_task(P, task, B, b, pend);
 		if (tau_out) {

@@ -153,8 +153,12 @@ DI bool certify_gram_lower(const real* G, real abs2, real rel2) {
 // singularity bookkeeping of the one MotionForceTask that went through the branch, kept in registers until the robot is
 // known to finish in this kernel (flush_singular)
 struct SingPend {
+	// set by the kernel: is this call one that commits the once-per-model-update bookkeeping (the fused tick, updateTaskModel:
+	// classifySingularity runs in SingularityHandler::updateTaskModel), and one that computes torques (the type-2 direction
+	// memory changes in computeTorques, :339-345)?
+	int commit, store_t2;
 	int task;  // -1: none
-	int clear, write_prior, ntypes, idx, word, count, size, c1, c2;
+	int clear, write_prior, ring, ntypes, idx, word, count, size, c1, c2;
 	int t2mask;	 // bit 2 i: store MFT_T2DIR + i, bit 2 i + 1: the value is +1 (else -1)
 };
 struct SingArgs {
@@ -403,10 +407,10 @@ DI bool singular_part(const Fact& f, const SingArgs& sa, real* Y, const real* JP
 	// ---- bookkeeping (classifySingularity, :230-295)
 	const int prev_types = ldi(t.istate, IS_NTYPES, B, b);
 	sp.task = sa.ti;
-	sp.clear = sp.write_prior = sp.t2mask = 0;
+	sp.clear = sp.write_prior = sp.t2mask = sp.ring = 0;
 	sp.ntypes = sp.idx = sp.word = sp.count = sp.size = sp.c1 = sp.c2 = 0;
 	if (reg) {	// the SVD says: not singular after all
-		sp.clear = prev_types != 0;
+		sp.clear = sp.commit && prev_types != 0;
 		if (!sp.clear) sp.task = -1;
 		return least > 1e-280;
 	}
@@ -415,7 +419,7 @@ DI bool singular_part(const Fact& f, const SingArgs& sa, real* Y, const real* JP
 	real q[N];
 	UNROLL for (int i = 0; i < N; i++) q[i] = ld(P.q, i, B, b);
 	const int ring_word = ldi(t.istate, (ring_count % t.sh_cap) >> 5, B, b);
-	sp.write_prior = (prev_types == 0 || c2 > c1);
+	sp.write_prior = sp.commit && (prev_types == 0 || c2 > c1);
 	// V_s = Xs / sigma with the sign convention shared with the oracle (largest-magnitude component positive)
 	real v[N], us[M];
 	{
@@ -430,12 +434,12 @@ DI bool singular_part(const Fact& f, const SingArgs& sa, real* Y, const real* JP
 		UNROLL for (int i = 0; i < N; i++) v[i] = vs * Xc[K * N + i];
 		UNROLL for (int r = 0; r < M; r++) us[r] = sgn * ws[r];
 	}
-	bool any1;
-	{
+	bool any1 = false;
+	if (sp.commit) {  // (computeTorques behind updateTaskModel of the same state classifies nothing)
 		// the pose at q: parked in LDS by the Jacobian sweep where the lane's column has room for it (position and two
 		// columns of the rotation), recomputed otherwise
 		real x0[3], R0[9];
-		if (POSE_SLOTS == 9 && t.frame_rigid) {
+		if (POSE_SLOTS == 9 && sa.pose && t.frame_rigid) {
 			UNROLL for (int k = 0; k < 3; k++) {
 				x0[k] = sa.pose[k * 64];
 				R0[3 * k] = sa.pose[(3 + k) * 64];
@@ -479,7 +483,7 @@ DI bool singular_part(const Fact& f, const SingArgs& sa, real* Y, const real* JP
 		any1 = t.sv_sign == SAI2B_SV_SIGN_BOTH ? (moved[0] && moved[1]) : (moved[0] || moved[1]);
 	}
 	CSTAMP_ANY(55);
-	{  // history ring (:276-293), stored by flush_singular
+	if (sp.commit) {  // history ring (:276-293), stored by flush_singular
 		int count = ring_count, size = ring_size;
 		const int cap = t.sh_cap;
 		const int idx = count % cap;
@@ -500,7 +504,7 @@ DI bool singular_part(const Fact& f, const SingArgs& sa, real* Y, const real* JP
 			word &= ~bit;
 			c2++;
 		}
-		sp.idx = idx >> 5, sp.word = word, sp.count = (count + 1) % (cap * 32768), sp.size = size, sp.c1 = c1, sp.c2 = c2, sp.ntypes = 1;
+		sp.idx = idx >> 5, sp.word = word, sp.count = (count + 1) % (cap * 32768), sp.size = size, sp.c1 = c1, sp.c2 = c2, sp.ntypes = 1, sp.ring = 1;
 	}
 	CSTAMP_ANY(56);
 	// ---- posture task in the singular joint direction (:152-157): yp = Q' L^-1 v, and the joint strategy (:327-351)
@@ -543,7 +547,7 @@ DI bool singular_part(const Fact& f, const SingArgs& sa, real* Y, const real* JP
 				hl = fma(v[i], ut, hl);
 				hd = fma(v[i], um, hd);
 			}
-			sp.t2mask = type1 ? 0 : mask;
+			sp.t2mask = (type1 || !sp.store_t2) ? 0 : mask;
 		}
 		real lam = 1.0 / npp;  // Lambda_joint_s
 		if (bie) {			   // Lambda_joint_s_modified = (Jpost M_BIE^-1 Jpost^T)^-1, Jpost^T = L yp (:202-205)
@@ -595,6 +599,7 @@ DI void flush_singular(const DevParams& P, int B, int b, const SingPend& sp) {
 	}
 	for (int i = 0; i < N; i++)
 		if (sp.t2mask & (1 << (2 * i))) st(t.state, MFT_T2DIR + i, B, b, (sp.t2mask & (2 << (2 * i))) ? 1.0 : -1.0);
+	if (!sp.ring) return;
 	sti(IS, sp.idx, B, b, sp.word);
 	sti(IS, IS_COUNT, B, b, sp.count);
 	sti(IS, IS_SIZE, B, b, sp.size);
@@ -1083,7 +1088,7 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 			// MotionForceTask::updateTaskModel / computeTorques (MotionForceTask.cpp:247-509) in the fully
 			// non-singular branch of the SingularityHandler (SingularityHandler.cpp:100-141,307-309)
 			CSTAMP(10);
-			constexpr bool SING = !TASK && MCAP <= 3;
+			constexpr bool SING = MCAP <= 3;
 			const bool inlane = SING && sp != nullptr;
 			const int prev_types = ldi(t.istate, IS_NTYPES, B, b);
 			if (!inlane) ok = ok && (prev_types == 0);
@@ -1128,7 +1133,7 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 			SingArgs sa;
 			SingPend none;
 			none.task = 0;	// "taken": singular_part declines
-			sa.P = &P, sa.t = &t, sa.ti = ti, sa.B = B, sa.b = b, sa.enabled = inlane, sa.pu = nullptr, sa.sp = inlane ? sp : &none, sa.pose = pend + LDS_SLOTS * 64;
+			sa.P = &P, sa.t = &t, sa.ti = ti, sa.B = B, sa.b = b, sa.enabled = inlane, sa.pu = nullptr, sa.sp = inlane ? sp : &none, sa.pose = TASK ? nullptr : pend + LDS_SLOTS * 64;
 			const int task_before = sa.sp->task;
 			{
 				real nn = 0;
@@ -1151,7 +1156,7 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 				// certified, with singularity history: the robot has left the region and the history goes (:239-245)
 				if (sp->task >= 0) {
 					ok = false;
-				} else {
+				} else if (sp->commit) {
 					sp->task = ti, sp->clear = 1;
 				}
 			}

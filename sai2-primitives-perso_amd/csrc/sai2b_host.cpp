@@ -90,6 +90,7 @@ struct sai2b_ctx {
 	double* sim_tau = nullptr;	// staging for host torques / bias read-back of the simulation harness
 	// task-level calls (TemplateTask.h:42-88): per task the caller's N_prec, the task's N and N * N_prec of the
 	// last sai2b_task_update_model, its torques and a staging copy of a host tau_prec; created on first use
+	int last_call_task = 0;	  // the last launch sequence was a task-level call: 1 = task_cert_kernel + work list, 2 = the generic task kernel alone
 	int* tk_count = nullptr;  // work list of the task-level SVD-free kernel (task_cert_kernel): 2 alternating counters + B robot indices
 	int* tk_list = nullptr;
 	int tk_parity = 0;
@@ -1105,6 +1106,7 @@ static unsigned refresh_otg_gating(sai2b_ctx* ctx) {
 static int fetch_rows(sai2b_ctx* ctx, const double* src, size_t row0, size_t rows, double* dst);
 
 static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torque) {
+	ctx->last_call_task = 0;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	for (int t = 0; t < ctx->T; t++) ctx->tio[t].standalone = ctx->tio[t].model_fresh = false;
 	const unsigned gated = refresh_otg_gating(ctx);
@@ -1274,16 +1276,19 @@ static int launch_task_call(sai2b_ctx* ctx, int task, const double* Np, const do
 			if ((rc = dev_alloc(ctx, &ctx->tk_list, (size_t)ctx->B))) return rc;
 		}
 		ctx->tk_parity ^= 1;
-		if (sai2b_launch_task_cert(ctx->d_params, ctx->B, task, rows, Np, tp, tau_out, N_out, Ntot_out, do_torque, ctx->tk_count, ctx->tk_list,
+		if (sai2b_launch_task_cert(ctx->d_params, ctx->B, task, rows, Np, tp, tau_out, N_out, Ntot_out,
+								   (do_torque ? 1 : 0) | (commit_sh ? 2 : 0) | (ctx->no_inlane_singular ? 4 : 0), ctx->tk_count, ctx->tk_list,
 								   ctx->tk_parity, ctx->stream) ||
 			sai2b_launch_task(ctx->d_params, ctx->B, task, Np, tp, tau_out, N_out, Ntot_out, commit_sh, do_torque, ctx->tk_count + ctx->tk_parity,
 							  ctx->tk_list, ctx->stream))
 			return set_error(ctx, SAI2B_RUNTIME_ERROR, "task launch failed");
 		ctx->launches += 2;
+		ctx->last_call_task = 1;
 		return SAI2B_OK;
 	}
 	if (sai2b_launch_task(ctx->d_params, ctx->B, task, Np, tp, tau_out, N_out, Ntot_out, commit_sh, do_torque, nullptr, nullptr, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "task launch failed");
+	ctx->last_call_task = 2;
 	ctx->launches++;
 	return SAI2B_OK;
 }
@@ -1758,6 +1763,15 @@ extern "C" int sai2b_get_fallback_count(sai2b_ctx* ctx, int* robots) {
 	if (!ctx || !robots) return set_error(ctx, SAI2B_INVALID_ARGUMENT, "sai2b_get_fallback_count: bad arguments");
 	if (int rc_ = flush_update(ctx)) return rc_;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (ctx->last_call_task) {	// a TemplateTask call came last: its own work list
+		if (ctx->last_call_task == 2) {
+			*robots = ctx->B;
+			return SAI2B_OK;
+		}
+		HIP_TRY(ctx, hipMemcpyAsync(robots, ctx->tk_count + ctx->tk_parity, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		return SAI2B_OK;
+	}
 	if (ctx->last_tick_generic_only) {	// no SVD-free kernel ran in front: every robot took the generic kernel
 		*robots = ctx->B;
 		return SAI2B_OK;

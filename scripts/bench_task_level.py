@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """A manual hierarchy (examples 04 / 18: MotionForceTask, then JointTask in its nullspace, tasks driven through the
 TemplateTask calls) on 65 536 robots: the nullspace chained through the host as the reference's Eigen code does it,
-chained on the device (sai2b_device_buffer(SAI2B_BUF_TASK_N_TOTAL)), and the same hierarchy as one fused tick."""
+chained on the device (sai2b_device_buffer(SAI2B_BUF_TASK_N_TOTAL)), and the same hierarchy as one fused tick.
+`python scripts/bench_task_level.py 4`: the three tasks of BASELINE config 4 with its poses (one robot in ten near a
+singularity: the task-level kernel keeps them, round 3; SAI2B_NO_INLANE_SINGULAR=1 for the work-list route)."""
 import os
 import sys
 import time
@@ -14,24 +16,29 @@ import torch  # noqa: F401
 import sai2_primitives_perso_amd as pkg
 
 B = 65536
-inp = pkg.workloads.make_inputs(3, B=B)
+CONFIG = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+inp = pkg.workloads.make_inputs(CONFIG, B=B)
+T = len(inp["tasks"])
 c = pkg.Controller(pkg.panda_model(), pkg.task_configs(inp["tasks"]), B)
 pkg.workloads.load_inputs(c, inp)
-t0_dev, t1_dev = (torch.empty((7, B), dtype=torch.float64, device="cuda") for _ in range(2))
+t_dev = [torch.empty((7, B), dtype=torch.float64, device="cuda") for _ in range(T)]
+t0_dev = t_dev[0]
 
 
 def host_chain():
     c.task_update_model(0, None)
-    c.task_update_model(1, c.task_nullspaces(0)[2])
-    return c.task_compute_torques(0) + c.task_compute_torques(1)
+    for t in range(1, T):
+        c.task_update_model(t, c.task_nullspaces(t - 1)[2])
+    return sum(c.task_compute_torques(t) for t in range(T))
 
 
 def device_chain():
     c.task_update_model(0, None)
-    c.task_update_model_behind(1, 0)
-    c.task_compute_torques(0, out=t0_dev)
-    c.task_compute_torques(1, out=t1_dev)
-    return t0_dev + t1_dev
+    for t in range(1, T):
+        c.task_update_model_behind(t, t - 1)
+    for t in range(T):
+        c.task_compute_torques(t, out=t_dev[t])
+    return sum(t_dev[1:], t_dev[0])
 
 
 def fused():

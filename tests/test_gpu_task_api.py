@@ -102,6 +102,61 @@ def test_compute_torques_with_tau_prec_matches_controller():
     assert e[ok].max() < 1e-9 and e.max() < 1e-6
 
 
+def test_manual_chain_with_robots_inside_a_blending_region(monkeypatch):
+    """the hand-chained hierarchy of the C4 workload (one robot in ten near a singularity) over four periods with the
+    state moving: the task-level SVD-free kernel keeps the robots inside a blending region too (round 3: the handler's
+    singular branch in whitened coordinates; updateTaskModel commits the singularity bookkeeping, computeTorques behind it
+    only reads it). Torques per task, the three nullspaces and the handler's counters against the oracle, for every
+    robot to the regular robots' tolerance; SAI2B_NO_INLANE_SINGULAR=1 (the generic task kernel behind a work list)
+    must agree."""
+    B = 1024 + 13
+    inp = pkg.workloads.make_inputs(4, B=B, seed=4500)
+    go, gg = ol.task_configs(inp["tasks"]), pkg.task_configs(inp["tasks"])
+    o = ol.Oracle(ol.panda_model(), go, B, threads=8)
+    g = pkg.Controller(pkg.panda_model(), gg, B)
+    monkeypatch.setenv("SAI2B_NO_INLANE_SINGULAR", "1")
+    h = pkg.Controller(pkg.panda_model(), gg, B)
+    monkeypatch.delenv("SAI2B_NO_INLANE_SINGULAR")
+    for c in (o, g, h):
+        ol.load_inputs(c, inp)
+    rng = np.random.default_rng(9)
+    dq0 = inp["dq"].copy()
+    seen = 0
+    for period in range(4):
+        q = inp["q"] + 0.002 * period * rng.normal(size=inp["q"].shape)
+        res = []
+        for c in (o, g, h):
+            c.set_state(q, dq0)
+            Nprec, tau, parts, nulls = None, np.zeros((N, B)), [], []
+            for t in range(3):
+                c.task_update_model(t, Nprec)
+                nulls.append(c.task_nullspaces(t))
+                Nprec = nulls[-1][2]
+            for t in range(3):
+                tt = c.task_compute_torques(t, tau)
+                parts.append(tt)
+                tau = tau + tt
+            res.append((tau, parts, nulls))
+        _, _, ro = o.get_mft_singularity(0)
+        sing = ro < 3
+        seen += int(sing.sum())
+        _, c1o, c2o = o.get_mft_sh_state(0)
+        for c, (tau, parts, nulls) in zip((g, h), res[1:]):
+            for a, b in zip(parts, res[0][1]):
+                assert _err(a, b).max() < TOL, (period, _err(a, b).max())
+            for na, nb in zip(nulls, res[0][2]):
+                for a, b in zip(na, nb):
+                    assert np.abs(a - b).max() < 1e-9
+            n, c1, c2 = c.get_mft_singularity_state(0)
+            assert np.array_equal(n > 0, sing) and np.array_equal(c1, c1o) and np.array_equal(c2, c2o)
+        # the last call was computeTorques of the full JointTask at the bottom; look at the MotionForceTask's own calls
+        for c, lo, hi in ((g, 0, 2), (h, int(sing.sum()), B)):
+            c.task_update_model(0, None)
+            assert lo <= c.fallback_count() <= hi, (c.fallback_count(), lo, hi)
+        o.task_update_model(0, None)  # (keeps the oracle's history in step with the two extra model updates)
+    assert seen > 4 * B // 30
+
+
 def test_example_01_single_joint_task():
     """BASELINE config 1 as the example drives it: one JointTask, N_prec = identity, computeTorques(),
     gains / goal changes between ticks, reInitializeTask; known answer A-KA 1 with full decoupling"""
