@@ -617,6 +617,122 @@ DI void flush_singular(const DevParams& P, int B, int b, const SingPend& sp) {
 // bounded-inertia ones: Jp^T x = LB (YB x), YB = LB^-1 Jp^T overwrites Jp) -> Gram-Schmidt of Y ->
 // Lambda term as L (Z R^-T a) -> downdate of Q.
 // TORQUE = false: the cascade alone (certificate and Q), for the range pass ahead of the trajectory generators.
+// The same level for tasks of 4 to 6 rows, where Y (42 doubles) and R beside Jp, L and Q do not fit the register file
+// (round 2: 1.1 KB of scratch per lane in the 6-row instantiation): Y is never stored. Pass 1 builds the rows of Jp
+// (Jp^T = L Q L^-1 Jr^T) for the certificate and the torque terms that need Jp; pass 2 is the Gram-Schmidt one column at a
+// time with the running projector doing the orthogonalisation: y'_c = Q_c (L^-1 jp_c) is already orthogonal to the
+// columns before it once their directions are out of Q (Q_c = Q - sum_k<c z_k z_k^T), so z_c = y'_c / |y'_c| with
+// r_cc = |y'_c|, and the Lambda term L Z R^-T a needs no stored Z or R either: with w = sum_k<c z_k u_k,
+// u_c = (a_c - w . y_c) / r_cc  (sum_k R_kc u_k = w . y_c, and w . y_c = w . L^-1 jp_c because w lies in range(Q)).
+// The bounded-inertia term comes last and overwrites Jp. One triangular solve per row more than level(), 80 live doubles fewer.
+template <int M, bool TORQUE = true>
+DI bool level_streamed(const Fact& f, const real* Jr, bool first, bool last, bool do_cert, real abs2, real rel2, int decoupling,
+					   bool has_va, const real* va, const real* vf, const real* vd, real* Q, real* tau) {
+	real JP[M * N];
+	UNROLL for (int c = 0; c < M; c++) {
+		if (first) {
+			UNROLL for (int i = 0; i < N; i++) JP[c * N + i] = Jr[c * N + i];
+		} else {
+			real col[N], y[N];
+			UNROLL for (int i = 0; i < N; i++) col[i] = Jr[c * N + i];
+			solve_lower<N>(f.L, f.dL, col);
+			UNROLL for (int i = 0; i < N; i++) {
+				real s = 0;
+				UNROLL for (int j = 0; j < N; j++) s = fma(symat(Q, i, j), col[j], s);
+				y[i] = s;
+			}
+			UNROLL for (int i = 0; i < N; i++) {  // row c of Jp = (L Y)^T
+				real s = 0;
+				UNROLL for (int k = 0; k <= i; k++) s = fma(f.L[i * N + k], y[k], s);
+				JP[c * N + i] = s;
+			}
+		}
+		__builtin_amdgcn_sched_barrier(0);	// one column at a time
+	}
+	CSTAMP(20);
+	bool ok = true;
+	if (do_cert) {
+		real G[M * M];
+		UNROLL for (int i = 0; i < M; i++) UNROLL for (int j = 0; j <= i; j++) {
+			real s = 0;
+			UNROLL for (int l = 0; l < N; l++) s = fma(JP[i * N + l], JP[j * N + l], s);
+			G[i * M + j] = s;
+		}
+		ok = certify_gram_lower<M>(G, abs2, rel2);
+	}
+	SAI2B_PHASE();
+	CSTAMP(21);
+	const bool full = decoupling == SAI2B_FULL_DYNAMIC_DECOUPLING;
+	if constexpr (TORQUE) {	 // direct terms: Jp^T (vd (+ vf with IMPEDANCE))
+		const bool imp = decoupling == SAI2B_IMPEDANCE;
+		UNROLL for (int c = 0; c < M; c++) {
+			const real zc = vd[c] + (imp ? vf[c] : 0.0);
+			UNROLL for (int i = 0; i < N; i++) tau[i] = fma(JP[c * N + i], zc, tau[i]);
+		}
+	}
+	SAI2B_PHASE();
+	// Gram-Schmidt through the running projector, the Lambda term and the downdate of Q, a column at a time
+	{
+		real w[N];
+		UNROLL for (int i = 0; i < N; i++) w[i] = 0;
+		const bool lam = TORQUE && (has_va || full);
+		UNROLL for (int c = 0; c < M; c++) {
+			real y[N], z[N];
+			UNROLL for (int i = 0; i < N; i++) y[i] = JP[c * N + i];
+			solve_lower<N>(f.L, f.dL, y);  // y_c = L^-1 jp_c (in range(Q) as it was when the level began)
+			real wy = 0;
+			UNROLL for (int i = 0; i < N; i++) wy = fma(w[i], y[i], wy);
+			real nn = 0;
+			UNROLL for (int i = 0; i < N; i++) {
+				real s = 0;
+				UNROLL for (int j = 0; j < N; j++) s = fma(symat(Q, i, j), y[j], s);
+				z[i] = s;
+				nn = fma(s, s, nn);
+			}
+			const real r = rsqrt(nn);
+			UNROLL for (int i = 0; i < N; i++) z[i] *= r;
+			if (lam) {
+				const real u = ((has_va ? va[c] : 0.0) + (full ? vf[c] : 0.0) - wy) * r;
+				UNROLL for (int i = 0; i < N; i++) w[i] = fma(z[i], u, w[i]);
+			}
+			// (the running projector is needed by the next column even at the last level; the last column's downdate is not)
+			if (!last || c + 1 < M) {
+				UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) Q[i * N + j] = fma(-z[i], z[j], Q[i * N + j]);
+			}
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		if (lam) add_l_times(f.L, w, tau);	// Jp^T Lambda a = L Z R^-T a
+	}
+	CSTAMP(23);
+	if (TORQUE && decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES) {
+		// Lambda_mod = (YB^T YB)^-1, YB = LB^-1 Jp^T (overwrites Jp); torques Jp^T x = LB (YB x)
+		solve_lb_columns<M>(f.lb, JP);
+		real AB[M * M], LA[M * M], dA[M], y[M];
+		UNROLL for (int i = 0; i < M; i++) UNROLL for (int j = 0; j <= i; j++) {
+			real s = 0;
+			UNROLL for (int l = 0; l < N; l++) s = fma(JP[i * N + l], JP[j * N + l], s);
+			AB[i * M + j] = s;
+		}
+		chol<M>(AB, LA, dA);
+		UNROLL for (int c = 0; c < M; c++) y[c] = vf[c];
+		solve_lower<M>(LA, dA, y);
+		solve_lower_t<M>(LA, dA, y);
+		real w[N];
+		UNROLL for (int i = 0; i < N; i++) {
+			real s = 0;
+			UNROLL for (int c = 0; c < M; c++) s = fma(JP[c * N + i], y[c], s);
+			w[i] = s;
+		}
+		UNROLL for (int i = 0; i < N; i++) {
+			real s = 0;
+			UNROLL for (int k = 0; k <= i; k++) s = fma(f.lb[(i * (i + 1) / 2 + k) * 64], w[k], s);
+			tau[i] += s;
+		}
+	}
+	CSTAMP(24);
+	return ok;
+}
+
 // SING: a level whose certificate fails goes through singular_part (MotionForceTasks of the small instantiation).
 template <int M, bool TORQUE = true, bool SING = false>
 DI bool level(const Fact& f, const real* Jr, bool first, bool last, bool do_cert, real abs2, real rel2, int decoupling,
@@ -754,6 +870,9 @@ DI bool level_any(int m, const Fact& f, const real* Jr, bool first, bool last, b
 	if constexpr (M > 1) {
 		if (m < M) return level_any<M - 1, TORQUE, SING>(m, f, Jr, first, last, do_cert, abs2, rel2, decoupling, has_va, va, vf, vd, Q, tau, sa);
 	}
+#ifndef SAI2B_NO_STREAMED_LEVEL	 // A/B (scripts/micro/cert_variants.sh)
+	if constexpr (M > 3) return level_streamed<M, TORQUE>(f, Jr, first, last, do_cert, abs2, rel2, decoupling, has_va, va, vf, vd, Q, tau);
+#endif
 	return level<M, TORQUE, SING>(f, Jr, first, last, do_cert, abs2, rel2, decoupling, has_va, va, vf, vd, Q, tau, sa);
 }
 
