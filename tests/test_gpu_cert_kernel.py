@@ -120,6 +120,29 @@ def test_singular_branch_in_the_kernel_follows_robots_in_and_out_of_the_region()
     assert seen_in > 20 * B // 10 and seen_out > 20 * B // 10, (seen_in, seen_out)
 
 
+@pytest.mark.parametrize("name", ["c4", "partial_mft_mixed", "jt_first"])
+def test_singular_branch_for_projected_and_lower_level_tasks(name):
+    """the in-lane singular branch where the MotionForceTask is not a first-level, axis-aligned position task: a partial
+    task whose motion space is not spanned by coordinate axes (rows PU^T J: the singular column of U goes back to the six
+    task coordinates through PU for the classification) and a MotionForceTask BEHIND a JointTask (Q is not the identity
+    when the level begins). Every robot to 1e-9, next to none through the work list."""
+    import zlib
+
+    import test_gpu_parity as tp
+
+    B = 2048
+    inp = tp._custom_inputs(tp.HIERARCHIES[name], B, seed=zlib.crc32(name.encode()) % 1000, singular_fraction=0.05)
+    o, g = _pair(inp)
+    for c in (o, g):
+        ol.load_inputs(c, inp)
+    for tick in range(3):
+        tau_o, tau_g = o.tick(), g.tick()
+        sing = _singular(o, inp)
+        assert sing.sum() >= 20
+        assert _err(tau_g, tau_o).max() < 1e-9, (tick, _err(tau_g, tau_o).max())
+        assert g.fallback_count() <= 4  # (two singular directions at once still go to the generic kernel)
+
+
 def test_cert_kernel_backs_off_when_it_declines_most_of_the_batch():
     """example 06's hierarchy on the sliding-base Panda ([partial JT(2), MFT(6), JT(8)]): most random poses are inside
     a blending region, the SVD-free kernel would only add its own time in front of the generic one. The host sees
