@@ -36,6 +36,28 @@ __global__ __launch_bounds__(64) SAI2B_GROUP_OCC void tick_group_kernel(const De
 	grp::tick_robot<G, RANGE>(P, b, pads[gi], commit_sh, with_comp, do_torque);
 }
 
+// the TemplateTask calls, lanes per robot (grp::task_robot); tk_count / tk_list as above
+template <int G>
+__global__ __launch_bounds__(64) SAI2B_GROUP_OCC void task_group_kernel(const DevParams* __restrict__ Pp, int task, const double* __restrict__ Nprec_in,
+														   const double* __restrict__ tau_prec, double* __restrict__ tau_out,
+														   double* __restrict__ N_out, double* __restrict__ Ntot_out, int commit_sh, int do_torque,
+														   const int* __restrict__ tk_count, const int* __restrict__ tk_list) {
+	constexpr int GPB = 64 / G;
+	__shared__ real pads[GPB][grp::PAD_DOUBLES];
+	const DevParams& P = *Pp;
+	const int gi = grp::group<G>();
+	if (tk_count) {
+		const int cnt = *(const gint*)tk_count;
+#pragma unroll 1
+		for (int e = blockIdx.x + gi * gridDim.x; e < cnt; e += gridDim.x * GPB)
+			grp::task_robot<G>(P, task, ((const gint*)tk_list)[e], pads[gi], Nprec_in, tau_prec, tau_out, N_out, Ntot_out, commit_sh, do_torque);
+		return;
+	}
+	const int b = blockIdx.x * GPB + gi;
+	if (b >= P.B) return;
+	grp::task_robot<G>(P, task, b, pads[gi], Nprec_in, tau_prec, tau_out, N_out, Ntot_out, commit_sh, do_torque);
+}
+
 }  // namespace sai2b
 
 #ifdef SAI2B_GROUP_STAMP
@@ -73,5 +95,22 @@ extern "C" int sai2b_launch_tick_group(const sai2b::DevParams* d_params, int B, 
 		else
 			hipLaunchKernelGGL((sai2b::tick_group_kernel<8, false>), grid, block, 0, stream, d_params, commit_sh, with_comp, do_torque, fb_count, fb_list);
 	}
+	return (int)hipGetLastError();
+}
+
+// the TemplateTask calls with a robot spread over `lanes` (16: a short work list, latency; 8: a whole batch, throughput)
+extern "C" int sai2b_launch_task_group(const sai2b::DevParams* d_params, int B, int lanes, int task, const double* Nprec_in, const double* tau_prec,
+									   double* tau_out, double* N_out, double* Ntot_out, int commit_sh, int do_torque, const int* tk_count,
+									   const int* tk_list, hipStream_t stream) {
+	const int gpb = 64 / lanes;
+	int blocks = (B + gpb - 1) / gpb;
+	if (tk_count && blocks > 1024) blocks = 1024;
+	const dim3 grid(blocks), block(64);
+	if (lanes == 16)
+		hipLaunchKernelGGL((sai2b::task_group_kernel<16>), grid, block, 0, stream, d_params, task, Nprec_in, tau_prec, tau_out, N_out, Ntot_out,
+						   commit_sh, do_torque, tk_count, tk_list);
+	else
+		hipLaunchKernelGGL((sai2b::task_group_kernel<8>), grid, block, 0, stream, d_params, task, Nprec_in, tau_prec, tau_out, N_out, Ntot_out,
+						   commit_sh, do_torque, tk_count, tk_list);
 	return (int)hipGetLastError();
 }

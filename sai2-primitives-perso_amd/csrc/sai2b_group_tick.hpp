@@ -335,7 +335,7 @@ DI void nullspace_T(const real* jpT, const real* L, const real* t1, int r, real*
 // SingularityHandler.cpp:75-368): mft_task of sai2b_device.hpp, rows in lanes. tau: this lane's component.
 template <int G>
 SAI2B_TASK_FN void mft_task_g(const DevParams& P, const DevTask& t, const Rob& rb, bool first, bool last, bool commit_sh, bool do_torque,
-				   real* nprecT, real& tau_total, ChainG& chain) {
+				   real* nprecT, real& tau_total, ChainG& chain, real* Ntask_out = nullptr) {
 	const int r = rb.r, B = rb.B, b = rb.b;
 	const bool r6 = r < 6, rN = r < N;
 	real x[3], R[9];
@@ -706,6 +706,9 @@ SAI2B_TASK_FN void mft_task_g(const DevParams& P, const DevTask& t, const Rob& r
 	}
 	tau_total += rN ? tau : 0.0;
 	GMARK(6, "mft_sing_done");
+	if (Ntask_out && rN) {	// getTaskNullspace (TemplateTask.h:73-77), task-level calls only: lane r holds column r
+		UNROLL for (int j = 0; j < N; j++) st(Ntask_out, j * N + r, B, b, ntaskT[j]);
+	}
 	if (!last) nprec_update<G>(first, ntaskT, nprecT);
 	GMARK(7, "mft_end");
 }
@@ -714,7 +717,7 @@ SAI2B_TASK_FN void mft_task_g(const DevParams& P, const DevTask& t, const Rob& r
 // sai2b_device.hpp, rows in lanes
 template <int G, bool RANGE_ONLY = false>
 SAI2B_TASK_FN void jt_task_g(const DevParams& P, const DevTask& t, const Rob& rb, bool first, bool last, bool with_comp, bool do_torque,
-				  real* nprecT, real& tau_total, ChainG& chain) {
+				  real* nprecT, real& tau_total, ChainG& chain, real* Ntask_out = nullptr) {
 	const int r = rb.r, B = rb.B, b = rb.b;
 	const bool rN = r < N, rk = r < t.k0;
 	const int rs = rk ? r : 0;
@@ -862,6 +865,9 @@ SAI2B_TASK_FN void jt_task_g(const DevParams& P, const DevTask& t, const Rob& rb
 		if (!last) nullspace_T<G, N>(jpT, L, t1, r, ntaskT);
 	}
 	tau_total += rN ? tau : 0.0;
+	if (Ntask_out && rN) {
+		UNROLL for (int j = 0; j < N; j++) st(Ntask_out, j * N + r, B, b, ntaskT[j]);
+	}
 	if (!last) nprec_update<G>(first, ntaskT, nprecT);
 	GMARK(12, "jt_end");
 }
@@ -927,6 +933,67 @@ DI void tick_robot(const DevParams& P, int b, real* pad, int commit_sh, int with
 			jt_task_g<G>(P, tk, rb, first, last, with_comp != 0, do_torque != 0, nprecT, tau, chain);
 	}
 	if (do_torque && rN) st(P.tau, rs, B, b, tau + g);	// RobotController.cpp:70-72
+}
+
+
+// The TemplateTask calls on ONE task under a caller-supplied N_prec (TemplateTask.h:42-88), a robot spread over G lanes: the
+// lanes-per-robot form of task_kernel (sai2b_kernels.hip), which it replaces behind task_cert_kernel's work list and for
+// the hierarchies that kernel does not take (round 3: the last user-reachable kernel with kilobytes of scratch per
+// lane is gone). Nothing is known about the tasks above: the range decisions take the Jacobi SVD (chain.ok = false), and a
+// JointTask applies the compensation term also behind an identity N_prec (first = false), as task_kernel does.
+template <int G>
+DI void task_robot(const DevParams& P, int task, int b, real* pad, const real* Nprec_in, const real* tau_prec, real* tau_out, real* N_out,
+				   real* Ntot_out, int commit_sh, int do_torque) {
+	const int B = P.B;
+	Rob rb;
+	rb.r = lane<G>();
+	rb.B = B;
+	rb.b = b;
+	rb.pad = pad;
+	const bool rN = rb.r < N;
+	const int rs = rN ? rb.r : 0;
+	rb.q = sel0(rN, ld(P.q, rs, B, b));
+	rb.dq = sel0(rN, ld(P.dq, rs, B, b));
+	real g = 0;
+	GMARK(13, "model_begin");
+	{
+		// Sai2Model::updateModel(): kinematics, M (CRBA), M^-1 (examples/05-using_robot_controller.cpp:143-145)
+		fk_scan<G>(P.model, rb.r, rb.q, rb.FR, rb.Fp);
+		GMARK(14, "model_fk_done");
+		real Mrow[N];
+		crba_g<G>(P.model, rb.r, rb.FR, rb.Fp, Mrow, false, &g);
+		GMARK(15, "model_crba_done");
+		UNROLL for (int j = 0; j < N; j++) rb.minv[j] = Mrow[j];
+		spd_inverse_rows<G, N>(rb.minv);
+		GMARK(16, "model_minv_done");
+		// bounded inertia estimate (SingularityHandler.cpp:176-182, JointTask.cpp:254-260), shared
+		const bool any_bie = P.any_bie != 0;  // (host: upload_params)
+		const real thr = P.bie_thr;
+		if (any_bie) {
+			UNROLL for (int j = 0; j < N; j++) rb.minvB[j] = (j == rb.r) ? fmax(Mrow[j], thr) : Mrow[j];
+			spd_inverse_rows<G, N>(rb.minvB);
+		} else {
+			UNROLL for (int j = 0; j < N; j++) rb.minvB[j] = rb.minv[j];
+		}
+	}
+	GMARK(17, "model_end");
+	real nprecT[N];
+	UNROLL for (int j = 0; j < N; j++) nprecT[j] = rN ? (Nprec_in ? ld(Nprec_in, j * N + rs, B, b) : kd(rb.r, j)) : 0.0;
+	const real tp = (rN && tau_prec) ? ld(tau_prec, rs, B, b) : 0.0;
+	real tau = tp;
+	ChainG chain;
+	chain.ok = false;
+	chain.wrows = 0;
+	UNROLL for (int j = 0; j < N; j++) chain.W[j] = 0;
+	const DevTask& tk = P.task[task];
+	if (tk.type == SAI2B_MOTION_FORCE_TASK)
+		mft_task_g<G>(P, tk, rb, false, false, commit_sh != 0, do_torque != 0, nprecT, tau, chain, N_out);
+	else
+		jt_task_g<G>(P, tk, rb, false, false, tau_prec != nullptr, do_torque != 0, nprecT, tau, chain, N_out);
+	if (Ntot_out && rN) {
+		UNROLL for (int j = 0; j < N; j++) st(Ntot_out, j * N + rs, B, b, nprecT[j]);
+	}
+	if (do_torque && tau_out && rN) st(tau_out, rs, B, b, tau - tp);
 }
 
 }  // namespace grp

@@ -1266,6 +1266,22 @@ static int task_cert_rows(const sai2b_ctx* ctx, int task) {
 }
 // one TemplateTask call on the device: the SVD-free kernel with the generic one over the robots it declined, or the
 // generic one for every robot
+// the generic form of a task-level call: a robot spread over 16 lanes (a work list) or 8 (a whole batch), or — SAI2B_GENERIC_LANES=1,
+// the A/B switch — the one-lane-per-robot task_kernel of rounds 1 and 2
+static int launch_task_generic(sai2b_ctx* ctx, int task, const double* Np, const double* tp, double* tau_out, double* N_out, double* Ntot_out,
+							   int commit_sh, int do_torque, const int* count, const int* list) {
+	// (introspection: the one-lane kernel is the instantiation that fills the per-task debug outputs)
+	// A whole batch stays on the one-lane kernel unless SAI2B_GENERIC_LANES asks otherwise: without the row-space chain of a
+	// controller tick every JointTask behind another task takes the 7 x 7 Jacobi, and 65 536 robots through the hand-chained
+	// [MFT, JT] cost 1 111 us per period with 8 lanes per robot against 692 us with one (profiles/r03_bench_task_level.txt)
+	int lanes = ctx->introspection ? 0 : generic_lanes(ctx, count == nullptr);
+	if (!count && ctx->generic_lanes_env == 0) lanes = 0;
+	if (lanes)
+		return sai2b_launch_task_group(ctx->d_params, ctx->B, lanes, task, Np, tp, tau_out, N_out, Ntot_out, commit_sh, do_torque, count, list,
+									   ctx->stream);
+	return sai2b_launch_task(ctx->d_params, ctx->B, task, Np, tp, tau_out, N_out, Ntot_out, commit_sh, do_torque, count, list, ctx->stream);
+}
+
 static int launch_task_call(sai2b_ctx* ctx, int task, const double* Np, const double* tp, double* tau_out, double* N_out, double* Ntot_out,
 							int commit_sh, int do_torque) {
 	const int rows = task_cert_rows(ctx, task);
@@ -1279,14 +1295,13 @@ static int launch_task_call(sai2b_ctx* ctx, int task, const double* Np, const do
 		if (sai2b_launch_task_cert(ctx->d_params, ctx->B, task, rows, Np, tp, tau_out, N_out, Ntot_out,
 								   (do_torque ? 1 : 0) | (commit_sh ? 2 : 0) | (ctx->no_inlane_singular ? 4 : 0), ctx->tk_count, ctx->tk_list,
 								   ctx->tk_parity, ctx->stream) ||
-			sai2b_launch_task(ctx->d_params, ctx->B, task, Np, tp, tau_out, N_out, Ntot_out, commit_sh, do_torque, ctx->tk_count + ctx->tk_parity,
-							  ctx->tk_list, ctx->stream))
+			launch_task_generic(ctx, task, Np, tp, tau_out, N_out, Ntot_out, commit_sh, do_torque, ctx->tk_count + ctx->tk_parity, ctx->tk_list))
 			return set_error(ctx, SAI2B_RUNTIME_ERROR, "task launch failed");
 		ctx->launches += 2;
 		ctx->last_call_task = 1;
 		return SAI2B_OK;
 	}
-	if (sai2b_launch_task(ctx->d_params, ctx->B, task, Np, tp, tau_out, N_out, Ntot_out, commit_sh, do_torque, nullptr, nullptr, ctx->stream))
+	if (launch_task_generic(ctx, task, Np, tp, tau_out, N_out, Ntot_out, commit_sh, do_torque, nullptr, nullptr))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "task launch failed");
 	ctx->last_call_task = 2;
 	ctx->launches++;
@@ -1318,7 +1333,7 @@ extern "C" int sai2b_task_compute_torques(sai2b_ctx* ctx, int task, const double
 	if (d.otg_on) {	 // the task's generator advances once per torque computation, before the law
 		if (((gated >> task) & 1) && !io.model_fresh) {
 			// is the JointTask's range empty for this robot now (JointTask.cpp:302-306)? models of the current state, nothing committed
-			if (sai2b_launch_task(ctx->d_params, ctx->B, task, Np, nullptr, nullptr, io.N, io.Ntot, 0, 0, nullptr, nullptr, ctx->stream))
+			if (launch_task_generic(ctx, task, Np, nullptr, nullptr, io.N, io.Ntot, 0, 0, nullptr, nullptr))
 				return set_error(ctx, SAI2B_RUNTIME_ERROR, "task-range pass launch failed");
 			ctx->launches++;
 		}

@@ -24,6 +24,9 @@ extern "C" int sai2b_launch_reinit(const sai2b::DevParams* d_params, int B, int 
 // one task on its own (TemplateTask.h:42-88): model update (do_torque = 0) or the task's torques (do_torque = 1) under
 // a caller-supplied N_prec ([49][B], NULL = identity) and tau_prec ([7][B], NULL = the no-argument computeTorques());
 // N_out / Ntot_out [49][B]: the task's nullspace and N * N_prec; tau_out [7][B]
+extern "C" int sai2b_launch_task_group(const sai2b::DevParams* d_params, int B, int lanes, int task, const double* Nprec_in, const double* tau_prec,
+									   double* tau_out, double* N_out, double* Ntot_out, int commit_sh, int do_torque, const int* tk_count,
+									   const int* tk_list, hipStream_t stream);
 extern "C" int sai2b_launch_task(const sai2b::DevParams* d_params, int B, int task, const double* Nprec_in, const double* tau_prec,
 								 double* tau_out, double* N_out, double* Ntot_out, int commit_sh, int do_torque, const int* tk_count,
 								 const int* tk_list, hipStream_t stream);
