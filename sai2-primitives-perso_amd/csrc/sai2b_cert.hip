@@ -99,13 +99,13 @@ __global__ __launch_bounds__(64) void task_cert_kernel(const DevParams* __restri
 // the same two alternating counters protocol as above.
 template <int MCAP>
 __global__ __launch_bounds__(64) void range_cert_kernel(const DevParams* __restrict__ Pp, int* __restrict__ rg_counts, int* __restrict__ rg_list,
-													   int parity) {
+													   int parity, int inlane) {
 	const DevParams& P = *Pp;
 	const int B = P.B;
 	const int b = blockIdx.x * 64 + threadIdx.x;
 	if (blockIdx.x == 0 && threadIdx.x == 0) ((gint*)rg_counts)[1 - parity] = 0;
 	if (b >= B) return;
-	const bool mine = cert::range_tick<MCAP>(P, P.model, B, b);
+	const bool mine = cert::range_tick<MCAP>(P, P.model, B, b, inlane != 0);
 	const unsigned long long declined = __ballot(!mine);
 	if (declined) {
 		int base = 0;
@@ -132,13 +132,14 @@ extern "C" int sai2b_debug_read_cstamps(unsigned long long* out, int cap) {
 }
 #endif
 
-extern "C" int sai2b_launch_range_cert(const sai2b::DevParams* d_params, int B, int max_rows, int* rg_counts, int* rg_list, int parity,
+// inlane: robots inside a blending region of a 2- or 3-row MotionForceTask stay in the kernel (cert::singular_range)
+extern "C" int sai2b_launch_range_cert(const sai2b::DevParams* d_params, int B, int max_rows, int* rg_counts, int* rg_list, int parity, int inlane,
 									   hipStream_t stream) {
 	const dim3 grid((B + 63) / 64), block(64);
 	if (max_rows <= 3)
-		hipLaunchKernelGGL(sai2b::range_cert_kernel<3>, grid, block, 0, stream, d_params, rg_counts, rg_list, parity);
+		hipLaunchKernelGGL(sai2b::range_cert_kernel<3>, grid, block, 0, stream, d_params, rg_counts, rg_list, parity, inlane);
 	else
-		hipLaunchKernelGGL(sai2b::range_cert_kernel<6>, grid, block, 0, stream, d_params, rg_counts, rg_list, parity);
+		hipLaunchKernelGGL(sai2b::range_cert_kernel<6>, grid, block, 0, stream, d_params, rg_counts, rg_list, parity, 0);
 	return (int)hipGetLastError();
 }
 

@@ -578,6 +578,78 @@ DI bool singular_part(const Fact& f, const SingArgs& sa, real* Y, const real* JP
 	return least > 1e-280 && npp > 1e-280;
 }
 
+// The cascade alone through a singular level (the range pass ahead of the trajectory generators, cert::range_tick): the
+// directions the level takes out of Q — the regular block's and the posture task's — without forces, torques or
+// bookkeeping. Same scope and same decisions as singular_part.
+template <int M>
+DI bool singular_range(const Fact& f, const SingArgs& sa, const real* Y, const real* JP, real* Q) {
+	constexpr int K = M - 1;
+	const DevTask& t = *sa.t;
+	real X[N * M], W[M * M];
+	UNROLL for (int c = 0; c < M; c++) UNROLL for (int i = 0; i < N; i++) X[i * M + c] = JP[c * N + i];
+	hestenes<N, M>(X, W);
+	real sv[M];
+	UNROLL for (int j = 0; j < M; j++) {
+		real a = 0;
+		UNROLL for (int r = 0; r < N; r++) a = fma(X[r * M + j], X[r * M + j], a);
+		sv[j] = sqrt(a);
+	}
+	real s0 = 0, s_last = 0, s_prev = 0;
+	int js = 0;
+	UNROLL for (int j = 0; j < M; j++) {
+		int p = 0;
+		UNROLL for (int k = 0; k < M; k++) p += (sv[k] > sv[j] || (sv[k] == sv[j] && k < j)) ? 1 : 0;
+		s0 = fmax(s0, sv[j]);
+		js = (p == M - 1) ? j : js;
+		s_last = (p == M - 1) ? sv[j] : s_last;
+		s_prev = (p == M - 2) ? sv[j] : s_prev;
+	}
+	if (s0 < t.s_abs_tol) return false;
+	if (M > 2 && s_prev / s0 < t.s_max) return false;
+	const bool reg = !(s_last / s0 < t.s_max);
+	if (!reg && !t.enforce) return false;
+	// Y' = Y U in the order [regular block | js], Gram-Schmidt of the block (and of the last column when it is regular)
+	real Yc[M * N], v[N];
+	UNROLL for (int k = 0; k < M; k++) UNROLL for (int i = 0; i < N; i++) {
+		real y = 0;
+		UNROLL for (int r = 0; r < M; r++) {
+			real u = 0;
+			if (k < K) {
+				u = (js <= k) ? W[r * M + (k + 1 < M ? k + 1 : k)] : W[r * M + k];
+			} else {
+				UNROLL for (int j = 0; j < M; j++) u = (js == j) ? W[r * M + j] : u;
+			}
+			y = fma(Y[r * N + i], u, y);
+		}
+		Yc[k * N + i] = y;
+	}
+	UNROLL for (int i = 0; i < N; i++) {
+		real x = 0;
+		UNROLL for (int j = 0; j < M; j++) x = (js == j) ? X[i * M + j] : x;
+		v[i] = x;  // sigma v_s: the scale does not matter to a direction
+	}
+	bool on[M];
+	UNROLL for (int k = 0; k < M; k++) on[k] = (k < K) ? true : reg;
+	real R[M * M], rinv[M];
+	real least = masked_gram_schmidt<M>(Yc, on, R, rinv);
+	UNROLL for (int c = 0; c < M; c++)
+		UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) Q[i * N + j] = fma(-Yc[c * N + i], Yc[c * N + j], Q[i * N + j]);
+	if (reg) return least > 1e-280;
+	// the posture direction y_p = Q' L^-1 v_s
+	real yp[N];
+	solve_lower<N>(f.L, f.dL, v);
+	real npp = 0;
+	UNROLL for (int i = 0; i < N; i++) {
+		real a = 0;
+		UNROLL for (int k = 0; k < N; k++) a = fma(symat(Q, i, k), v[k], a);
+		yp[i] = a;
+		npp = fma(a, a, npp);
+	}
+	const real r2 = 1.0 / npp;
+	UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) Q[i * N + j] = fma(-yp[i] * r2, yp[j], Q[i * N + j]);
+	return least > 1e-280 && npp > 1e-280;
+}
+
 // the deferred bookkeeping of singular_part, for a robot that finishes in this kernel
 DI void flush_singular(const DevParams& P, int B, int b, const SingPend& sp) {
 	if (sp.task < 0) return;
@@ -772,8 +844,13 @@ DI bool level(const Fact& f, const real* Jr, bool first, bool last, bool do_cert
 		}
 		ok = certify_gram_lower<M>(G, abs2, rel2);
 	}
-	if constexpr (SING && TORQUE && M >= 2) {	 // (a one-row task has no blending region: it is regular or fully singular)
-		if (sa->enabled && !ok) return singular_part<M>(f, *sa, Y, JP, first, last, decoupling, vf, vd, Q, tau);
+	if constexpr (SING && M >= 2) {	 // (a one-row task has no blending region: it is regular or fully singular)
+		if (sa->enabled && !ok) {
+			if constexpr (TORQUE)
+				return singular_part<M>(f, *sa, Y, JP, first, last, decoupling, vf, vd, Q, tau);
+			else
+				return singular_range<M>(f, *sa, Y, JP, Q);
+		}
 	}
 	SAI2B_PHASE();
 	CSTAMP(21);
@@ -1436,8 +1513,9 @@ DI void flush_task(const DevParams& P, int task, int B, int b, const real* pend)
 // level carries its certificate has all its rows in its range (active); a full one at the bottom is active while
 // rows are left. Returns false when some level could not be certified: the caller hands the robot to the range pass
 // of the generic kernel, which decides (and overwrites) with the reference's own rule.
+// inlane: robots inside a blending region of a 2- or 3-row MotionForceTask stay (singular_range), as in tick()
 template <int MCAP, class MD>
-DI bool range_tick(const DevParams& P, const MD& md, int B, int b) {
+DI bool range_tick(const DevParams& P, const MD& md, int B, int b, bool inlane = false) {
 	Fact f;
 	f.lb = nullptr;
 	real q[N];
@@ -1481,14 +1559,18 @@ DI bool range_tick(const DevParams& P, const MD& md, int B, int b) {
 			if (wrows + m > N) ok = false;
 			const real abs2 = t.s_abs_tol * t.s_abs_tol, rel2 = t.s_max * t.s_max;
 			bool c_ok;
+			constexpr bool SING = MCAP <= 3;
+			SingArgs sa;
+			sa.P = &P, sa.t = &t, sa.ti = ti, sa.B = B, sa.b = b, sa.enabled = SING && inlane, sa.fnorm = 0, sa.pu = nullptr, sa.pose = nullptr, sa.sp = nullptr;
 			if (t.full_projection || t.p_lead < 6) {
-				c_ok = level_any<(MCAP < 6 ? MCAP : 6), false>(m, f, Jw, first, last, true, abs2, rel2, t.decoupling, false, zero, zero, zero, Q, tau);
+				c_ok = level_any<(MCAP < 6 ? MCAP : 6), false, SING>(m, f, Jw, first, last, true, abs2, rel2, t.decoupling, false, zero, zero, zero, Q, tau, &sa);
 			} else {
 				real Jr[6 * N];
 				mm_tn<6, 6, N>(t.PU, Jw, Jr);
-				c_ok = level_any<(MCAP < 6 ? MCAP : 6), false>(m, f, Jr, first, last, true, abs2, rel2, t.decoupling, false, zero, zero, zero, Q, tau);
+				c_ok = level_any<(MCAP < 6 ? MCAP : 6), false, SING>(m, f, Jr, first, last, true, abs2, rel2, t.decoupling, false, zero, zero, zero, Q, tau, &sa);
 			}
-			ok = ok & c_ok & (n_types == 0);
+			// (singularity history does not enter a range decision; without the in-lane branch such a robot is the generic pass's)
+			ok = ok & c_ok & (sa.enabled || n_types == 0);
 			wrows += m;
 		} else if (t.full_selection) {
 			if (t.otg_gated) st(t.otg_state, OTG_ACTIVE, B, b, wrows < N ? 1.0 : 0.0);

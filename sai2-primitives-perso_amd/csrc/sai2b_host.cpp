@@ -1119,7 +1119,7 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 		// for the robots it can certify and only the others take the generic kernel's range pass
 		const int ck = (ctx->introspection || ctx->cert_backoff > 0) ? 0 : cert_kind(ctx);
 		if (ck) {
-			if (sai2b_launch_range_cert(ctx->d_params, ctx->B, ck - 3, ctx->rg_counts, ctx->rg_list, ctx->rg_parity, ctx->stream) ||
+			if (sai2b_launch_range_cert(ctx->d_params, ctx->B, ck - 3, ctx->rg_counts, ctx->rg_list, ctx->rg_parity, ctx->no_inlane_singular ? 0 : 1, ctx->stream) ||
 				sai2b_launch_tick_group(ctx->d_params, ctx->B, 16, 1, 0, with_comp, 0, ctx->rg_counts + ctx->rg_parity, ctx->rg_list, ctx->stream))
 				return set_error(ctx, SAI2B_RUNTIME_ERROR, "task-range pass launch failed");
 			ctx->rg_parity ^= 1;

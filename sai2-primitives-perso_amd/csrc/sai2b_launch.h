@@ -16,7 +16,7 @@ extern "C" int sai2b_launch_tick_cert(const sai2b::DevParams* d_params, int B, i
 									  int parity, hipStream_t stream);
 // the range pass ahead of the trajectory generators for certified robots (sai2b_cert.hip: range_cert_kernel); the rest
 // of the batch goes to rg_list for sai2b_launch_tick_group(..., range_only = 1, ...)
-extern "C" int sai2b_launch_range_cert(const sai2b::DevParams* d_params, int B, int max_rows, int* rg_counts, int* rg_list, int parity,
+extern "C" int sai2b_launch_range_cert(const sai2b::DevParams* d_params, int B, int max_rows, int* rg_counts, int* rg_list, int parity, int inlane,
 									   hipStream_t stream);
 extern "C" int sai2b_launch_range_pass(const sai2b::DevParams* d_params, int B, int debug, int with_comp, int group, hipStream_t stream);
 // only_task < 0: every task (RobotController::reinitializeTasks); else TemplateTask::reInitializeTask of that one
