@@ -13,22 +13,27 @@ namespace sai2b {
 // not carry the register footprint of a 6- or 7-row level.
 // (The robot constants are read from the parameter block: compiling the stock Panda in, as tick_fast_kernel does,
 // measured 9 % SLOWER here — 53.2 vs 49.0 us on the same box — the literals cost registers this kernel does not have.)
-template <int MCAP>
+// fb_counts[2 + parity]: how many robots went through the in-lane singular branch (cleared and filled like the work list's count)
+template <int MCAP, bool S6 = false>
 __global__ __launch_bounds__(64) void tick_cert_kernel(const DevParams* __restrict__ Pp, int with_comp, int* __restrict__ fb_counts,
 													  int* __restrict__ fb_list, int parity) {
 	__shared__ real pend_lds[(cert::LDS_SLOTS + (MCAP <= 3 ? cert::POSE_SLOTS : 0)) * 64];
 	const DevParams& P = *Pp;
 	const int B = P.B;
 	const int b = blockIdx.x * 64 + threadIdx.x;
-	if (blockIdx.x == 0 && threadIdx.x == 0) ((gint*)fb_counts)[1 - parity] = 0;
+	if (blockIdx.x == 0 && threadIdx.x == 0) ((gint*)fb_counts)[1 - parity] = 0, ((gint*)fb_counts)[2 + (1 - parity)] = 0;
 	if (b >= B) return;
 	real* pend = pend_lds + threadIdx.x;
 	real tau[N];
 	// with_comp: bit 0 = JointTask compensation of the tasks above, bit 1 = singular MotionForceTasks go to the work list
 	// instead of through cert::singular_part (SAI2B_NO_INLANE_SINGULAR=1, the A/B switch)
 	cert::SingPend sp;
-	sp.task = -1, sp.commit = 1, sp.store_t2 = 1;
-	const bool mine = cert::tick<MCAP, cert::DM>(P, P.model, B, b, (with_comp & 1) != 0, pend, tau, nullptr, (with_comp & 2) ? nullptr : &sp);
+	sp.task = -1, sp.commit = 1, sp.store_t2 = 1, sp.took = 0;
+	const bool mine = cert::tick<MCAP, cert::DM, DevModel, false, S6>(P, P.model, B, b, (with_comp & 1) != 0, pend, tau, nullptr, (with_comp & 2) ? nullptr : &sp);
+	{
+		const unsigned long long took = __ballot(sp.took != 0);
+		if (took && threadIdx.x == 0) atomicAdd(&fb_counts[2 + parity], __popcll(took));  // lane 0 is always in range
+	}
 	const unsigned long long declined = __ballot(!mine);
 	if (declined) {
 		int base = 0;
@@ -40,7 +45,7 @@ __global__ __launch_bounds__(64) void tick_cert_kernel(const DevParams* __restri
 		}
 	}
 	cert::flush(P, B, b, pend);
-	if constexpr (MCAP <= 3) cert::flush_singular(P, B, b, sp);
+	cert::flush_singular(P, B, b, sp);
 	UNROLL for (int i = 0; i < N; i++) st(P.tau, i, B, b, tau[i] + pend[i * 64]);  // RobotController.cpp:70-72
 }
 
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(64) void task_cert_kernel(const DevParams* __restri
 	io.write_active = do_torque ? 0 : 1;
 	real tau[N];
 	cert::SingPend sp;
-	sp.task = -1, sp.commit = (call_bits >> 1) & 1, sp.store_t2 = do_torque;
+	sp.task = -1, sp.commit = (call_bits >> 1) & 1, sp.store_t2 = do_torque, sp.took = 0;
 	const bool mine = cert::tick<MCAP, cert::DM, DevModel, true>(P, P.model, B, b, tau_prec != nullptr, pend, tau, &io, (call_bits & 4) ? nullptr : &sp);
 	const unsigned long long declined = __ballot(!mine);
 	if (declined) {
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(64) void task_cert_kernel(const DevParams* __restri
 			return;
 		}
 	}
-	if constexpr (MCAP <= 3) cert::flush_singular(P, B, b, sp);
+	cert::flush_singular(P, B, b, sp);
 	if (do_torque) {
 		cert::flush_task(P, task, B, b, pend);
 		if (tau_out) {
@@ -159,9 +164,12 @@ extern "C" int sai2b_launch_task_cert(const sai2b::DevParams* d_params, int B, i
 extern "C" int sai2b_launch_tick_cert(const sai2b::DevParams* d_params, int B, int max_rows, int with_comp, int* fb_counts, int* fb_list,
 									  int parity, hipStream_t stream) {
 	const dim3 grid((B + 63) / 64), block(64);
+	// with_comp bit 2: the 6-row instantiation with the singular branch in the lane (cert::tick<.., S6>)
 	if (max_rows <= 3)
-		hipLaunchKernelGGL(sai2b::tick_cert_kernel<3>, grid, block, 0, stream, d_params, with_comp, fb_counts, fb_list, parity);
+		hipLaunchKernelGGL((sai2b::tick_cert_kernel<3>), grid, block, 0, stream, d_params, with_comp, fb_counts, fb_list, parity);
+	else if (with_comp & 4)
+		hipLaunchKernelGGL((sai2b::tick_cert_kernel<6, true>), grid, block, 0, stream, d_params, with_comp, fb_counts, fb_list, parity);
 	else
-		hipLaunchKernelGGL(sai2b::tick_cert_kernel<6>, grid, block, 0, stream, d_params, with_comp, fb_counts, fb_list, parity);
+		hipLaunchKernelGGL((sai2b::tick_cert_kernel<6>), grid, block, 0, stream, d_params, with_comp, fb_counts, fb_list, parity);
 	return (int)hipGetLastError();
 }

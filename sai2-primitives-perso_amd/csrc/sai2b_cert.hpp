@@ -157,6 +157,7 @@ struct SingPend {
 	// classifySingularity runs in SingularityHandler::updateTaskModel), and one that computes torques (the type-2 direction
 	// memory changes in computeTorques, :339-345)?
 	int commit, store_t2;
+	int took;  // out: the robot went through the singular branch (the host's choice of kernel looks at how many do)
 	int task;  // -1: none
 	int clear, write_prior, ring, ntypes, idx, word, count, size, c1, c2;
 	int t2mask;	 // bit 2 i: store MFT_T2DIR + i, bit 2 i + 1: the value is +1 (else -1)
@@ -275,135 +276,19 @@ DI void add_l_times(const real* L, const real* w, real* tau) {
 	}
 }
 
-// Y, JP: what level() built (Y = L^-1 Jp^T by columns, JP = rows of Jp); fu / ff: unit mass force and force related terms in
-// the task's reduced coordinates. Adds the level's torques to tau and takes its directions out of Q. false: not handled.
-//
-// ONE singular direction (split = M - 1: every one of the 3 611 robots inside a blending region of the C4 workload), or none
-// after all (the certificate is sufficient, not necessary); two or more small singular values of a 2- or 3-row task go to the
-// work list. The columns are brought into the order [the M - 1 larger singular values | the smallest]: everything about
-// the regular block is then compile-time shaped like a level of M - 1 rows, the singular direction is one vector and its
-// Lambdas are scalars, and one flag (`reg`: the last column is regular too) is all that is left of the column masks.
+// The second half of the singular branch, shared by the two forms of the level (singular_part: tasks of 2 or 3 rows;
+// singular_streamed: 4 to 6): bookkeeping (classification by perturbed kinematics, history ring), the posture task in the
+// singular joint direction, the joint strategy, the blend, and the posture direction out of Q. xs: the singular column of
+// Xs = Jp^T U (= sigma v), ws: the singular column of U in the task's reduced coordinates, tau_s: the sanitised and
+// clamped singular-direction torques; Q: already without the regular block's directions (Q').
 template <int M>
-DI bool singular_part(const Fact& f, const SingArgs& sa, real* Y, const real* JP, bool first, bool last, int decoupling,
-					  const real* fu, const real* ff, real* Q, real* tau) {
-	constexpr int K = M - 1;
+DI bool singular_tail(const Fact& f, const SingArgs& sa, bool reg, real least, const real* xs, const real* ws, real s_last, real alpha,
+					  const real* tau_s, int decoupling, const real* fu, const real* ff, real* Q, real* tau) {
 	const DevParams& P = *sa.P;
 	const DevTask& t = *sa.t;
 	const int B = sa.B, b = sa.b;
 	SingPend& sp = *sa.sp;
-	if (sp.task >= 0) return false;	 // one per robot
-	CSTAMP_ANY(50);
-	// ---- thin SVD of Jp by one-sided Jacobi on Jp^T (SingularityHandler.cpp:78-81)
-	real X[N * M], W[M * M];
-	UNROLL for (int c = 0; c < M; c++) UNROLL for (int i = 0; i < N; i++) X[i * M + c] = JP[c * N + i];
-	hestenes<N, M>(X, W);
-	CSTAMP_ANY(51);
-	real sv[M];
-	UNROLL for (int j = 0; j < M; j++) {
-		real a = 0;
-		UNROLL for (int r = 0; r < N; r++) a = fma(X[r * M + j], X[r * M + j], a);
-		sv[j] = sqrt(a);
-	}
-	// positions in descending order (ties by index, as the oracle sorts); js: the column of the smallest singular value
-	real s0 = 0, s_last = 0, s_prev = 0;
-	int js = 0;
-	UNROLL for (int j = 0; j < M; j++) {
-		int p = 0;
-		UNROLL for (int k = 0; k < M; k++) p += (sv[k] > sv[j] || (sv[k] == sv[j] && k < j)) ? 1 : 0;
-		s0 = fmax(s0, sv[j]);
-		js = (p == M - 1) ? j : js;
-		s_last = (p == M - 1) ? sv[j] : s_last;
-		s_prev = (p == M - 2) ? sv[j] : s_prev;	 // (M = 2: position 0, the largest)
-	}
-	// ---- range split (:83-143): the first position i >= 1 with s_i / s_0 < s_max
-	if (s0 < t.s_abs_tol) return false;			   // fully singular: the task is passed through
-	if (M > 2 && s_prev / s0 < t.s_max) return false;  // two or more singular directions
-	const real icn = s_last / s0;
-	const bool reg = !(icn < t.s_max);	// not singular after all
-	const real alpha = reg ? 1.0 : fmin(fmax((icn - t.s_min) / (t.s_max - t.s_min), 0.0), 1.0);
-	if (!reg && !t.enforce) return false;
 	const bool bie = decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES, impedance = decoupling == SAI2B_IMPEDANCE;
-	// ---- columns in the order [regular block | js]: Xs (= Jp^T U), Y' = Y U, U^T F
-	real Xc[M * N], Yc[M * N], au[M], af[M], ws[M];
-	{
-		real Ur[M * M];	 // Ur[r * M + k]: component r of column k in the new order
-		UNROLL for (int k = 0; k < K; k++) UNROLL for (int r = 0; r < M; r++) Ur[r * M + k] = (js <= k) ? W[r * M + k + 1] : W[r * M + k];
-		UNROLL for (int r = 0; r < M; r++) {  // the last column: column js, by selects
-			real v = 0;
-			UNROLL for (int j = 0; j < M; j++) v = (js == j) ? W[r * M + j] : v;
-			Ur[r * M + K] = v;
-			ws[r] = v;
-		}
-		UNROLL for (int k = 0; k < M; k++) {
-			UNROLL for (int i = 0; i < N; i++) {
-				real v;
-				if (k < K) {
-					v = (js <= k) ? X[i * M + (k + 1 < M ? k + 1 : k)] : X[i * M + k];	// (k + 1 < M always holds here)
-				} else {
-					v = 0;
-					UNROLL for (int j = 0; j < M; j++) v = (js == j) ? X[i * M + j] : v;
-				}
-				Xc[k * N + i] = v;
-			}
-			real a = 0, c = 0;
-			UNROLL for (int r = 0; r < M; r++) {
-				a = fma(Ur[r * M + k], fu[r], a);
-				c = fma(Ur[r * M + k], ff[r], c);
-			}
-			au[k] = a, af[k] = c;
-			UNROLL for (int i = 0; i < N; i++) {
-				real y = 0;
-				UNROLL for (int r = 0; r < M; r++) y = fma(Y[r * N + i], Ur[r * M + k], y);
-				Yc[k * N + i] = y;
-			}
-		}
-	}
-	CSTAMP_ANY(52);
-	bool on[M];
-	UNROLL for (int k = 0; k < M; k++) on[k] = (k < K) ? true : reg;
-	// ---- Lambda_s_modified U_s^T Fu (scalar) and, with bounded inertia, Lambda_ns_modified U_ns^T Fu (:184-206)
-	real zs = 0, zn[M];
-	UNROLL for (int k = 0; k < M; k++) zn[k] = 0;
-	if (bie) {
-		real YB[M * N];
-		UNROLL for (int i = 0; i < M * N; i++) YB[i] = Xc[i];
-		solve_lb_columns<M>(f.lb, YB);
-		UNROLL for (int k = 0; k < M; k++) zn[k] = au[k];
-		masked_gram_solve<M>(YB, on, zn);
-		real g = 0;
-		UNROLL for (int i = 0; i < N; i++) g = fma(YB[K * N + i], YB[K * N + i], g);
-		zs = au[K] / g;
-	} else {
-		real g = 0;
-		UNROLL for (int i = 0; i < N; i++) g = fma(Yc[K * N + i], Yc[K * N + i], g);
-		zs = au[K] / g;	 // Lambda_s = (Jp_s M^-1 Jp_s^T)^-1 (:121)
-	}
-	CSTAMP_ANY(53);
-	// ---- singular-direction torques, sanitised and clamped (:354-365)
-	real tau_s[N];
-	UNROLL for (int i = 0; i < N; i++) {
-		real s = Xc[K * N + i] * (zs + af[K]);
-		s = (s != s) ? 0.0 : fmin(fmax(s, -P.model.effort[i]), P.model.effort[i]);
-		tau_s[i] = reg ? 0.0 : s;
-	}
-	// ---- non-singular torques (:321-322 = :307-309): direct terms through Xs, the Lambda_ns term through Z_ns
-	UNROLL for (int i = 0; i < N; i++) {
-		real s = 0;
-		UNROLL for (int k = 0; k < M; k++) s = fma(Xc[k * N + i], on[k] ? af[k] + (impedance ? au[k] : zn[k]) : 0.0, s);
-		tau[i] += s;
-	}
-	real R[M * M], rinv[M];
-	real least = masked_gram_schmidt<M>(Yc, on, R, rinv);
-	if (!bie && !impedance) {
-		real a[M], w[N];
-		UNROLL for (int k = 0; k < M; k++) a[k] = on[k] ? au[k] : 0.0;
-		gs_apply<M>(Yc, R, rinv, a, w);
-		add_l_times(f.L, w, tau);
-	}
-	// Q' = Q - Z_ns Z_ns^T
-	UNROLL for (int c = 0; c < M; c++)
-		UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) Q[i * N + j] = fma(-Yc[c * N + i], Yc[c * N + j], Q[i * N + j]);
-	CSTAMP_ANY(54);
 	// ---- bookkeeping (classifySingularity, :230-295)
 	const int prev_types = ldi(t.istate, IS_NTYPES, B, b);
 	sp.task = sa.ti;
@@ -425,13 +310,13 @@ DI bool singular_part(const Fact& f, const SingArgs& sa, real* Y, const real* JP
 	{
 		real big = 0, bigabs = -1;
 		UNROLL for (int i = 0; i < N; i++) {
-			const bool take = fabs(Xc[K * N + i]) > bigabs;
-			bigabs = take ? fabs(Xc[K * N + i]) : bigabs;
-			big = take ? Xc[K * N + i] : big;
+			const bool take = fabs(xs[i]) > bigabs;
+			bigabs = take ? fabs(xs[i]) : bigabs;
+			big = take ? xs[i] : big;
 		}
 		const real inv = s_last > 0 ? 1.0 / s_last : 0.0;
 		const real vs = big < 0 ? -inv : inv, sgn = big < 0 ? -1.0 : 1.0;
-		UNROLL for (int i = 0; i < N; i++) v[i] = vs * Xc[K * N + i];
+		UNROLL for (int i = 0; i < N; i++) v[i] = vs * xs[i];
 		UNROLL for (int r = 0; r < M; r++) us[r] = sgn * ws[r];
 	}
 	bool any1 = false;
@@ -578,6 +463,139 @@ DI bool singular_part(const Fact& f, const SingArgs& sa, real* Y, const real* JP
 	return least > 1e-280 && npp > 1e-280;
 }
 
+// Y, JP: what level() built (Y = L^-1 Jp^T by columns, JP = rows of Jp); fu / ff: unit mass force and force related terms in
+// the task's reduced coordinates. Adds the level's torques to tau and takes its directions out of Q. false: not handled.
+//
+// ONE singular direction (split = M - 1: every one of the 3 611 robots inside a blending region of the C4 workload), or none
+// after all (the certificate is sufficient, not necessary); two or more small singular values of a 2- or 3-row task go to the
+// work list. The columns are brought into the order [the M - 1 larger singular values | the smallest]: everything about
+// the regular block is then compile-time shaped like a level of M - 1 rows, the singular direction is one vector and its
+// Lambdas are scalars, and one flag (`reg`: the last column is regular too) is all that is left of the column masks.
+template <int M>
+DI bool singular_part(const Fact& f, const SingArgs& sa, real* Y, const real* JP, bool first, bool last, int decoupling,
+					  const real* fu, const real* ff, real* Q, real* tau) {
+	constexpr int K = M - 1;
+	const DevParams& P = *sa.P;
+	const DevTask& t = *sa.t;
+	const int B = sa.B, b = sa.b;
+	SingPend& sp = *sa.sp;
+	sp.took = 1;
+	if (sp.task >= 0) return false;	 // one per robot
+	CSTAMP_ANY(50);
+	// ---- thin SVD of Jp by one-sided Jacobi on Jp^T (SingularityHandler.cpp:78-81)
+	real X[N * M], W[M * M];
+	UNROLL for (int c = 0; c < M; c++) UNROLL for (int i = 0; i < N; i++) X[i * M + c] = JP[c * N + i];
+	hestenes<N, M>(X, W);
+	CSTAMP_ANY(51);
+	real sv[M];
+	UNROLL for (int j = 0; j < M; j++) {
+		real a = 0;
+		UNROLL for (int r = 0; r < N; r++) a = fma(X[r * M + j], X[r * M + j], a);
+		sv[j] = sqrt(a);
+	}
+	// positions in descending order (ties by index, as the oracle sorts); js: the column of the smallest singular value
+	real s0 = 0, s_last = 0, s_prev = 0;
+	int js = 0;
+	UNROLL for (int j = 0; j < M; j++) {
+		int p = 0;
+		UNROLL for (int k = 0; k < M; k++) p += (sv[k] > sv[j] || (sv[k] == sv[j] && k < j)) ? 1 : 0;
+		s0 = fmax(s0, sv[j]);
+		js = (p == M - 1) ? j : js;
+		s_last = (p == M - 1) ? sv[j] : s_last;
+		s_prev = (p == M - 2) ? sv[j] : s_prev;	 // (M = 2: position 0, the largest)
+	}
+	// ---- range split (:83-143): the first position i >= 1 with s_i / s_0 < s_max
+	if (s0 < t.s_abs_tol) return false;			   // fully singular: the task is passed through
+	if (M > 2 && s_prev / s0 < t.s_max) return false;  // two or more singular directions
+	const real icn = s_last / s0;
+	const bool reg = !(icn < t.s_max);	// not singular after all
+	const real alpha = reg ? 1.0 : fmin(fmax((icn - t.s_min) / (t.s_max - t.s_min), 0.0), 1.0);
+	if (!reg && !t.enforce) return false;
+	const bool bie = decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES, impedance = decoupling == SAI2B_IMPEDANCE;
+	// ---- columns in the order [regular block | js]: Xs (= Jp^T U), Y' = Y U, U^T F
+	real Xc[M * N], Yc[M * N], au[M], af[M], ws[M];
+	{
+		real Ur[M * M];	 // Ur[r * M + k]: component r of column k in the new order
+		UNROLL for (int k = 0; k < K; k++) UNROLL for (int r = 0; r < M; r++) Ur[r * M + k] = (js <= k) ? W[r * M + k + 1] : W[r * M + k];
+		UNROLL for (int r = 0; r < M; r++) {  // the last column: column js, by selects
+			real v = 0;
+			UNROLL for (int j = 0; j < M; j++) v = (js == j) ? W[r * M + j] : v;
+			Ur[r * M + K] = v;
+			ws[r] = v;
+		}
+		UNROLL for (int k = 0; k < M; k++) {
+			UNROLL for (int i = 0; i < N; i++) {
+				real v;
+				if (k < K) {
+					v = (js <= k) ? X[i * M + (k + 1 < M ? k + 1 : k)] : X[i * M + k];	// (k + 1 < M always holds here)
+				} else {
+					v = 0;
+					UNROLL for (int j = 0; j < M; j++) v = (js == j) ? X[i * M + j] : v;
+				}
+				Xc[k * N + i] = v;
+			}
+			real a = 0, c = 0;
+			UNROLL for (int r = 0; r < M; r++) {
+				a = fma(Ur[r * M + k], fu[r], a);
+				c = fma(Ur[r * M + k], ff[r], c);
+			}
+			au[k] = a, af[k] = c;
+			UNROLL for (int i = 0; i < N; i++) {
+				real y = 0;
+				UNROLL for (int r = 0; r < M; r++) y = fma(Y[r * N + i], Ur[r * M + k], y);
+				Yc[k * N + i] = y;
+			}
+		}
+	}
+	CSTAMP_ANY(52);
+	bool on[M];
+	UNROLL for (int k = 0; k < M; k++) on[k] = (k < K) ? true : reg;
+	// ---- Lambda_s_modified U_s^T Fu (scalar) and, with bounded inertia, Lambda_ns_modified U_ns^T Fu (:184-206)
+	real zs = 0, zn[M];
+	UNROLL for (int k = 0; k < M; k++) zn[k] = 0;
+	if (bie) {
+		real YB[M * N];
+		UNROLL for (int i = 0; i < M * N; i++) YB[i] = Xc[i];
+		solve_lb_columns<M>(f.lb, YB);
+		UNROLL for (int k = 0; k < M; k++) zn[k] = au[k];
+		masked_gram_solve<M>(YB, on, zn);
+		real g = 0;
+		UNROLL for (int i = 0; i < N; i++) g = fma(YB[K * N + i], YB[K * N + i], g);
+		zs = au[K] / g;
+	} else {
+		real g = 0;
+		UNROLL for (int i = 0; i < N; i++) g = fma(Yc[K * N + i], Yc[K * N + i], g);
+		zs = au[K] / g;	 // Lambda_s = (Jp_s M^-1 Jp_s^T)^-1 (:121)
+	}
+	CSTAMP_ANY(53);
+	// ---- singular-direction torques, sanitised and clamped (:354-365)
+	real tau_s[N];
+	UNROLL for (int i = 0; i < N; i++) {
+		real s = Xc[K * N + i] * (zs + af[K]);
+		s = (s != s) ? 0.0 : fmin(fmax(s, -P.model.effort[i]), P.model.effort[i]);
+		tau_s[i] = reg ? 0.0 : s;
+	}
+	// ---- non-singular torques (:321-322 = :307-309): direct terms through Xs, the Lambda_ns term through Z_ns
+	UNROLL for (int i = 0; i < N; i++) {
+		real s = 0;
+		UNROLL for (int k = 0; k < M; k++) s = fma(Xc[k * N + i], on[k] ? af[k] + (impedance ? au[k] : zn[k]) : 0.0, s);
+		tau[i] += s;
+	}
+	real R[M * M], rinv[M];
+	real least = masked_gram_schmidt<M>(Yc, on, R, rinv);
+	if (!bie && !impedance) {
+		real a[M], w[N];
+		UNROLL for (int k = 0; k < M; k++) a[k] = on[k] ? au[k] : 0.0;
+		gs_apply<M>(Yc, R, rinv, a, w);
+		add_l_times(f.L, w, tau);
+	}
+	// Q' = Q - Z_ns Z_ns^T
+	UNROLL for (int c = 0; c < M; c++)
+		UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) Q[i * N + j] = fma(-Yc[c * N + i], Yc[c * N + j], Q[i * N + j]);
+	CSTAMP_ANY(54);
+	return singular_tail<M>(f, sa, reg, least, Xc + K * N, ws, s_last, alpha, tau_s, decoupling, fu, ff, Q, tau);
+}
+
 // The cascade alone through a singular level (the range pass ahead of the trajectory generators, cert::range_tick): the
 // directions the level takes out of Q — the regular block's and the posture task's — without forces, torques or
 // bookkeeping. Same scope and same decisions as singular_part.
@@ -689,6 +707,242 @@ DI void flush_singular(const DevParams& P, int B, int b, const SingPend& sp) {
 // bounded-inertia ones: Jp^T x = LB (YB x), YB = LB^-1 Jp^T overwrites Jp) -> Gram-Schmidt of Y ->
 // Lambda term as L (Z R^-T a) -> downdate of Q.
 // TORQUE = false: the cascade alone (certificate and Q), for the range pass ahead of the trajectory generators.
+// ---- The singular branch for tasks of 4 to 6 rows (level_streamed) -----------------------------------------------
+// singular_part's column rotations of the 7 x 6 array Jp^T (and 36 numbers of U) do not fit beside L, Q and Jp (a first
+// version: 1.9 KB of scratch per lane, the branch 250 us). With ONE singular direction the handler needs less than an SVD:
+// the smallest singular triplet (sigma_s, u_s, v_s = Jp^T u_s / sigma_s), the largest and the second smallest singular values
+// for its decisions, and for everything regular only the SUBSPACE orthogonal to u_s — a regular level does not care about
+// an orthogonal change of its task coordinates. So:
+//   * eigenvalues of the M x M Gram matrix G = Jp Jp^T by cyclic two-sided Jacobi, values only (21 numbers in registers);
+//     absolute accuracy eps |G|, i.e. 1e-12 relative on the smallest one inside a blending region — it only feeds decisions
+//     with thresholds (s_max) and the blending weight alpha;
+//   * u_s by inverse iteration on G - mu I (mu just below the smallest eigenvalue: three iterations), sigma_s = |Jp^T u_s|
+//     from Jp itself;
+//   * a Householder reflector H with H e_M = +-u_s: the rows of H^T Jp are [an orthonormal mix of the regular directions |
+//     +-sigma_s v_s^T], the singular one LAST at compile time: the regular block is level_streamed's Gram-Schmidt through the
+//     running projector over M - 1 rows, the singular direction is one row and scalar Lambdas, the rest is singular_tail.
+// 1 / x and 1 / sqrt(x) from the hardware estimates with two Newton steps (a rotation angle does not need the IEEE division)
+DI real recip_nr(real x) {
+	real r = __builtin_amdgcn_rcp(x);
+	r = fma(fma(-x, r, 1.0), r, r);
+	return fma(fma(-x, r, 1.0), r, r);
+}
+DI real rsqrt_nr(real x) {
+	real r = __builtin_amdgcn_rsq(x);
+	const real h = 0.5 * x;
+	r = fma(fma(-h * r, r, 0.5), r, r);
+	return fma(fma(-h * r, r, 0.5), r, r);
+}
+template <int M>
+DI void sym_eigenvalues(real* G, real* lam) {  // G: lower triangle in M x M row-major storage, destroyed
+#pragma unroll 1
+	for (int sweep = 0; sweep < 30; sweep++) {
+		real off = 0, dia = 0;
+		UNROLL for (int i = 0; i < M; i++) {
+			dia = fma(G[i * M + i], G[i * M + i], dia);
+			UNROLL for (int j = 0; j < i; j++) off = fma(G[i * M + j], G[i * M + j], off);
+		}
+		if (!(off > 1e-26 * dia)) break;	// off-diagonal norm below 1e-13 of the diagonal's: the eigenvalues move by its square
+		UNROLL for (int p = 0; p < M - 1; p++) UNROLL for (int q = p + 1; q < M; q++) {
+			const real apq = G[q * M + p];
+			const real app = G[p * M + p], aqq = G[q * M + q];
+			// rotation that zeroes (p, q): t = sign(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq);
+			// written without the division by apq (a zero off-diagonal gives t = 0)
+			const real d = aqq - app, g2 = 2 * apq;
+			const real h2 = fma(d, d, g2 * g2);
+			const real den = fabs(d) + (h2 > 0 ? h2 * rsqrt_nr(h2) : 0.0);
+			const real t = den > 0 ? (d < 0 ? -g2 : g2) * recip_nr(den) : 0.0;
+			const real c = rsqrt_nr(fma(t, t, 1.0)), sn = c * t;
+			G[p * M + p] = fma(-t, apq, app);
+			G[q * M + q] = fma(t, apq, aqq);
+			G[q * M + p] = 0;
+			UNROLL for (int k = 0; k < M; k++) {
+				if (k != p && k != q) {
+					real& gkp = (k > p) ? G[k * M + p] : G[p * M + k];
+					real& gkq = (k > q) ? G[k * M + q] : G[q * M + k];
+					const real a = gkp, b2 = gkq;
+					gkp = fma(c, a, -sn * b2);
+					gkq = fma(sn, a, c * b2);
+				}
+			}
+		}
+	}
+	UNROLL for (int i = 0; i < M; i++) lam[i] = G[i * M + i];
+}
+
+template <int M>
+DI bool singular_streamed(const Fact& f, const SingArgs& sa, real* JP, int decoupling, const real* fu_in, const real* ff_in, real* Q,
+						  real* tau) {
+	const DevTask& t = *sa.t;
+	const DevParams& P = *sa.P;
+	SingPend& sp = *sa.sp;
+	sp.took = 1;
+	if (sp.task >= 0) return false;	 // one per robot
+	real us[M];
+	real s0, s_last, s_prev;
+	{
+		real G[M * M], lam[M];
+		UNROLL for (int i = 0; i < M; i++) UNROLL for (int j = 0; j <= i; j++) {
+			real a = 0;
+			UNROLL for (int l = 0; l < N; l++) a = fma(JP[i * N + l], JP[j * N + l], a);
+			G[i * M + j] = a;
+		}
+		sym_eigenvalues<M>(G, lam);
+		real l0 = 0, l1 = 1e300, l2 = 1e300;  // largest, smallest, second smallest
+		UNROLL for (int i = 0; i < M; i++) {
+			const real v = fmax(lam[i], 0.0);
+			l0 = fmax(l0, v);
+			const bool lt1 = v < l1;
+			l2 = lt1 ? l1 : fmin(l2, v);
+			l1 = lt1 ? v : l1;
+		}
+		s0 = sqrt(l0), s_prev = sqrt(l2);
+		if (s0 < t.s_abs_tol) return false;		  // fully singular: the task is passed through
+		if (s_prev / s0 < t.s_max) return false;  // two or more singular directions
+		// u_s: inverse iteration on G - mu I (Cholesky: the shifted matrix is positive definite by 1e-6 of its smallest eigenvalue,
+		// or by 1e-14 of the largest; the error shrinks by <= 1e-5 per iteration while the next eigenvalue is 1.2 times the smallest)
+		const real mu = l1 * (1.0 - 1e-6) - 1e-14 * l0;
+		real A[M * M], LA[M * M], dA[M];
+		UNROLL for (int i = 0; i < M; i++) UNROLL for (int j = 0; j <= i; j++) {
+			real a = (i == j) ? -mu : 0.0;
+			UNROLL for (int l = 0; l < N; l++) a = fma(JP[i * N + l], JP[j * N + l], a);
+			A[i * M + j] = a;
+		}
+		chol<M>(A, LA, dA);
+		UNROLL for (int i = 0; i < M; i++) us[i] = 1.0 + 0.37 * i;	// (any vector with a component along u_s)
+#pragma unroll 1
+		for (int it = 0; it < 4; it++) {
+			solve_lower<M>(LA, dA, us);
+			solve_lower_t<M>(LA, dA, us);
+			real nn = 0;
+			UNROLL for (int i = 0; i < M; i++) nn = fma(us[i], us[i], nn);
+			const real r = rsqrt(nn);
+			UNROLL for (int i = 0; i < M; i++) us[i] *= r;
+		}
+	}
+	// sigma_s v_s = Jp^T u_s
+	real xs[N];
+	UNROLL for (int i = 0; i < N; i++) {
+		real a = 0;
+		UNROLL for (int c = 0; c < M; c++) a = fma(JP[c * N + i], us[c], a);
+		xs[i] = a;
+	}
+	{
+		real a = 0;
+		UNROLL for (int i = 0; i < N; i++) a = fma(xs[i], xs[i], a);
+		s_last = sqrt(a);
+	}
+	const real icn = s_last / s0;
+	const bool reg = !(icn < t.s_max);	// not singular after all
+	const real alpha = reg ? 1.0 : fmin(fmax((icn - t.s_min) / (t.s_max - t.s_min), 0.0), 1.0);
+	if (!reg && !t.enforce) return false;
+	const bool bie = decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES, impedance = decoupling == SAI2B_IMPEDANCE;
+	const bool full = decoupling == SAI2B_FULL_DYNAMIC_DECOUPLING;
+	// Householder H = I - 2 w w^T with H e_M = sg u_s (sg = -sign(u_s[M-1]): no cancellation in u_s - sg e_M)
+	real fu[M], ff[M];
+	{
+		const real sg = us[M - 1] > 0 ? -1.0 : 1.0;
+		real w[M];
+		UNROLL for (int i = 0; i < M; i++) w[i] = us[i] * sg - ((i == M - 1) ? 1.0 : 0.0);	// sg u_s - e_M
+		real nn = 0;
+		UNROLL for (int i = 0; i < M; i++) nn = fma(w[i], w[i], nn);
+		const real beta = 2.0 / nn;
+		// rows: JP <- H^T JP = JP - beta w (w^T JP);  forces: H^T F
+		UNROLL for (int l = 0; l < N; l++) {
+			real a = 0;
+			UNROLL for (int c = 0; c < M; c++) a = fma(w[c], JP[c * N + l], a);
+			a *= beta;
+			UNROLL for (int c = 0; c < M; c++) JP[c * N + l] = fma(-w[c], a, JP[c * N + l]);
+		}
+		real au = 0, af = 0;
+		UNROLL for (int c = 0; c < M; c++) {
+			au = fma(w[c], fu_in[c], au);
+			af = fma(w[c], ff_in[c], af);
+		}
+		au *= beta, af *= beta;
+		UNROLL for (int c = 0; c < M; c++) {
+			fu[c] = fma(-w[c], au, fu_in[c]);
+			ff[c] = fma(-w[c], af, ff_in[c]);
+		}
+		// the last row is now sg sigma_s v_s^T, the last force coordinates sg u_s^T F: take the sign out
+		UNROLL for (int l = 0; l < N; l++) JP[(M - 1) * N + l] = xs[l];
+		fu[M - 1] *= sg, ff[M - 1] *= sg;
+	}
+	// ---- regular block: direct terms, then the Gram-Schmidt through the running projector (level_streamed, pass 2)
+	UNROLL for (int i = 0; i < N; i++) {
+		real a = 0;
+		UNROLL for (int k = 0; k < M; k++) a = fma(JP[k * N + i], (k < M - 1 || reg) ? ff[k] + (impedance ? fu[k] : 0.0) : 0.0, a);
+		tau[i] += a;
+	}
+	real least = 1e300, gs = 0;
+	{
+		real w[N];
+		UNROLL for (int i = 0; i < N; i++) w[i] = 0;
+		UNROLL for (int k = 0; k < M; k++) {
+			const bool on = (k < M - 1) || reg;
+			real y[N], z[N];
+			UNROLL for (int i = 0; i < N; i++) y[i] = JP[k * N + i];
+			solve_lower<N>(f.L, f.dL, y);
+			real wy = 0, yy = 0;
+			UNROLL for (int i = 0; i < N; i++) {
+				wy = fma(w[i], y[i], wy);
+				yy = fma(y[i], y[i], yy);
+			}
+			if (k == M - 1) gs = yy;  // Lambda_s = 1 / (y_s . y_s) (:121)
+			real nn = 0;
+			UNROLL for (int i = 0; i < N; i++) {
+				real a = 0;
+				UNROLL for (int j = 0; j < N; j++) a = fma(symat(Q, i, j), y[j], a);
+				z[i] = a;
+				nn = fma(a, a, nn);
+			}
+			least = on ? fmin(least, nn) : least;
+			const real r = on ? rsqrt(nn) : 0.0;
+			UNROLL for (int i = 0; i < N; i++) z[i] = on ? z[i] * r : 0.0;
+			if (full) {
+				const real u = (fu[k] - wy) * r;
+				UNROLL for (int i = 0; i < N; i++) w[i] = fma(z[i], u, w[i]);
+			}
+			UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) Q[i * N + j] = fma(-z[i], z[j], Q[i * N + j]);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		if (full) add_l_times(f.L, w, tau);
+	}
+	// ---- Lambda_s_modified U_s^T Fu (scalar); with bounded inertia the regular block's Lambda_ns_modified too (:184-206)
+	real zs = fu[M - 1] / gs;
+	if (bie) {
+		solve_lb_columns<M>(f.lb, JP);	// YB = LB^-1 Xs overwrites the rows
+		real g = 0;
+		UNROLL for (int i = 0; i < N; i++) g = fma(JP[(M - 1) * N + i], JP[(M - 1) * N + i], g);
+		zs = fu[M - 1] / g;
+		bool on[M];
+		UNROLL for (int k = 0; k < M; k++) on[k] = (k < M - 1) || reg;
+		real zn[M];
+		UNROLL for (int k = 0; k < M; k++) zn[k] = fu[k];
+		masked_gram_solve<M>(JP, on, zn);
+		real w[N];
+		UNROLL for (int i = 0; i < N; i++) {
+			real a = 0;
+			UNROLL for (int k = 0; k < M; k++) a = fma(JP[k * N + i], zn[k], a);  // (zn is zero outside the block)
+			w[i] = a;
+		}
+		UNROLL for (int i = 0; i < N; i++) {  // Jp_ns^T x = LB (YB x)
+			real a = 0;
+			UNROLL for (int k = 0; k <= i; k++) a = fma(f.lb[(i * (i + 1) / 2 + k) * 64], w[k], a);
+			tau[i] += a;
+		}
+	}
+	// ---- singular-direction torques, sanitised and clamped (:354-365)
+	real tau_s[N];
+	UNROLL for (int i = 0; i < N; i++) {
+		real a = xs[i] * (zs + ff[M - 1]);
+		a = (a != a) ? 0.0 : fmin(fmax(a, -P.model.effort[i]), P.model.effort[i]);
+		tau_s[i] = reg ? 0.0 : a;
+	}
+	// (singular_tail's force terms — the type-2 magnitude (F . u_s) / |F| — in the original task coordinates)
+	return singular_tail<M>(f, sa, reg, least, xs, us, s_last, alpha, tau_s, decoupling, fu_in, ff_in, Q, tau);
+}
+
 // The same level for tasks of 4 to 6 rows, where Y (42 doubles) and R beside Jp, L and Q do not fit the register file
 // (round 2: 1.1 KB of scratch per lane in the 6-row instantiation): Y is never stored. Pass 1 builds the rows of Jp
 // (Jp^T = L Q L^-1 Jr^T) for the certificate and the torque terms that need Jp; pass 2 is the Gram-Schmidt one column at a
@@ -697,9 +951,9 @@ DI void flush_singular(const DevParams& P, int B, int b, const SingPend& sp) {
 // r_cc = |y'_c|, and the Lambda term L Z R^-T a needs no stored Z or R either: with w = sum_k<c z_k u_k,
 // u_c = (a_c - w . y_c) / r_cc  (sum_k R_kc u_k = w . y_c, and w . y_c = w . L^-1 jp_c because w lies in range(Q)).
 // The bounded-inertia term comes last and overwrites Jp. One triangular solve per row more than level(), 80 live doubles fewer.
-template <int M, bool TORQUE = true>
+template <int M, bool TORQUE = true, bool SING = false>
 DI bool level_streamed(const Fact& f, const real* Jr, bool first, bool last, bool do_cert, real abs2, real rel2, int decoupling,
-					   bool has_va, const real* va, const real* vf, const real* vd, real* Q, real* tau) {
+					   bool has_va, const real* va, const real* vf, const real* vd, real* Q, real* tau, const SingArgs* sa = nullptr) {
 	real JP[M * N];
 	UNROLL for (int c = 0; c < M; c++) {
 		if (first) {
@@ -731,6 +985,9 @@ DI bool level_streamed(const Fact& f, const real* Jr, bool first, bool last, boo
 			G[i * M + j] = s;
 		}
 		ok = certify_gram_lower<M>(G, abs2, rel2);
+	}
+	if constexpr (SING && TORQUE) {
+		if (sa->enabled && !ok) return singular_streamed<M>(f, *sa, JP, decoupling, vf, vd, Q, tau);
 	}
 	SAI2B_PHASE();
 	CSTAMP(21);
@@ -948,7 +1205,7 @@ DI bool level_any(int m, const Fact& f, const real* Jr, bool first, bool last, b
 		if (m < M) return level_any<M - 1, TORQUE, SING>(m, f, Jr, first, last, do_cert, abs2, rel2, decoupling, has_va, va, vf, vd, Q, tau, sa);
 	}
 #ifndef SAI2B_NO_STREAMED_LEVEL	 // A/B (scripts/micro/cert_variants.sh)
-	if constexpr (M > 3) return level_streamed<M, TORQUE>(f, Jr, first, last, do_cert, abs2, rel2, decoupling, has_va, va, vf, vd, Q, tau);
+	if constexpr (M > 3) return level_streamed<M, TORQUE, SING>(f, Jr, first, last, do_cert, abs2, rel2, decoupling, has_va, va, vf, vd, Q, tau, sa);
 #endif
 	return level<M, TORQUE, SING>(f, Jr, first, last, do_cert, abs2, rel2, decoupling, has_va, va, vf, vd, Q, tau, sa);
 }
@@ -1191,7 +1448,10 @@ DI int q0_slot(int k) { return k < N ? k : (k < TASK_FREE ? k + 12 : LDS_SLOTS +
 
 // sp: the bookkeeping of a MotionForceTask that went through singular_part (the caller flushes it with the rest);
 // NULL: such robots go to the work list (MCAP = 6, the task-level calls, SAI2B_NO_INLANE_SINGULAR)
-template <int MCAP, int DCAP, class MD, bool TASK = false>
+// S6: the instantiation whose 4- to 6-row MotionForceTasks have the singular branch too (singular_streamed). A kernel of its
+// own, chosen by the host while many robots are inside a blending region (sai2b_host.cpp: launch_tick): the branch's
+// registers cost the REGULAR path of the 6-row kernel 45 -> 75 us, inlined, and more as a call.
+template <int MCAP, int DCAP, class MD, bool TASK = false, bool S6 = false>
 DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, real* pend, real* tau, const TaskArgs* io = nullptr,
 			 SingPend* sp = nullptr) {
 	CSTAMP(0);
@@ -1284,7 +1544,7 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 			// MotionForceTask::updateTaskModel / computeTorques (MotionForceTask.cpp:247-509) in the fully
 			// non-singular branch of the SingularityHandler (SingularityHandler.cpp:100-141,307-309)
 			CSTAMP(10);
-			constexpr bool SING = MCAP <= 3;
+			constexpr bool SING = MCAP <= 3 || S6;
 			const bool inlane = SING && sp != nullptr;
 			const int prev_types = ldi(t.istate, IS_NTYPES, B, b);
 			if (!inlane) ok = ok && (prev_types == 0);
@@ -1329,7 +1589,7 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 			SingArgs sa;
 			SingPend none;
 			none.task = 0;	// "taken": singular_part declines
-			sa.P = &P, sa.t = &t, sa.ti = ti, sa.B = B, sa.b = b, sa.enabled = inlane, sa.pu = nullptr, sa.sp = inlane ? sp : &none, sa.pose = TASK ? nullptr : pend + LDS_SLOTS * 64;
+			sa.P = &P, sa.t = &t, sa.ti = ti, sa.B = B, sa.b = b, sa.enabled = inlane, sa.pu = nullptr, sa.sp = inlane ? sp : &none, sa.pose = (TASK || MCAP > 3) ? nullptr : pend + LDS_SLOTS * 64;
 			const int task_before = sa.sp->task;
 			{
 				real nn = 0;

@@ -43,7 +43,9 @@ struct sai2b_ctx {
 	// lanes per robot of the generic kernel: SAI2B_GENERIC_LANES = 16 / 8 / 1 (1: the one-lane-per-robot kernel),
 	// default 0 = by the amount of work (generic_lanes())
 	int generic_lanes_env = 0;
-	int* fb_counts = nullptr;	// [2] robots the SVD-free kernel handed to the generic one (alternating by fb_parity)
+	// [4]: [0..1] robots the SVD-free kernel handed to the generic one (alternating by fb_parity), [2..3] robots that went through
+	// the in-lane singular branch of tick_cert_kernel (same alternation)
+	int* fb_counts = nullptr;
 	int* fb_list = nullptr;		// [B] their indices
 	int* rg_counts = nullptr;	// [2], rg_list [B]: the same for the range pass ahead of the trajectory generators
 	int* rg_list = nullptr;
@@ -53,7 +55,10 @@ struct sai2b_ctx {
 	// behind a partial JointTask is inside a blending region most of the time): every 8th such tick its count of
 	// declined robots comes back to the host (pinned word, never waited for); above 40 % of the batch the next 64
 	// ticks run the generic kernel alone, then the SVD-free kernel is tried again. Results are the same either way.
-	int* fb_seen = nullptr;		// pinned host word
+	int* fb_seen = nullptr;		// pinned host words: [0] declined, [1] through the in-lane singular branch
+	// many robots inside a blending region of a 4- to 6-row MotionForceTask: the 6-row SVD-free kernel with the singular branch in
+	// the lane runs instead of the hierarchy's usual first kernel (launch_tick); SAI2B_NO_SING6=1 switches the mode off
+	bool sing_mode = false, no_sing6 = false;
 	hipEvent_t fb_seen_ev = nullptr;
 	bool fb_seen_pending = false;
 	int cert_probe = 0, cert_backoff = 0;
@@ -679,6 +684,8 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	ctx->no_task_cert = ntc && ntc[0] == '1';
 	const char* nis = std::getenv("SAI2B_NO_INLANE_SINGULAR");
 	ctx->no_inlane_singular = nis && nis[0] == '1';
+	const char* ns6 = std::getenv("SAI2B_NO_SING6");
+	ctx->no_sing6 = ns6 && ns6[0] == '1';
 	const char* pc = std::getenv("SAI2B_PREFER_CERT");
 	ctx->prefer_cert = pc && pc[0] == '1';
 	if (const char* gl = std::getenv("SAI2B_GENERIC_LANES")) ctx->generic_lanes_env = std::atoi(gl);
@@ -705,11 +712,12 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	if ((rc = dev_alloc(ctx, &ctx->tau, N * Bs))) return rc;
 	hp.q = ctx->q, hp.dq = ctx->dq, hp.tau = ctx->tau;
 	if ((rc = dev_alloc(ctx, &ctx->q_pose, (size_t)N * Bs))) return rc;
-	if ((rc = dev_alloc(ctx, &ctx->fb_counts, 2))) return rc;
+	if ((rc = dev_alloc(ctx, &ctx->fb_counts, 4))) return rc;
 	if ((rc = dev_alloc(ctx, &ctx->fb_list, Bs))) return rc;
 	if ((rc = dev_alloc(ctx, &ctx->rg_counts, 2))) return rc;
 	if ((rc = dev_alloc(ctx, &ctx->rg_list, Bs))) return rc;
-	HIP_TRY(ctx, hipHostMalloc((void**)&ctx->fb_seen, sizeof(int), hipHostMallocDefault));
+	HIP_TRY(ctx, hipHostMalloc((void**)&ctx->fb_seen, 2 * sizeof(int), hipHostMallocDefault));
+	ctx->fb_seen[0] = ctx->fb_seen[1] = 0;
 	HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fb_seen_ev, hipEventDisableTiming));
 	if ((rc = dev_alloc(ctx, &ctx->otg_counts, 2 * SAI2B_MAX_TASKS))) return rc;
 	if ((rc = dev_alloc(ctx, &ctx->otg_list, SAI2B_MAX_TASKS * Bs))) return rc;
@@ -1054,6 +1062,14 @@ static int fast_kind(const sai2b_ctx* ctx) {
 	return (ctx->cfg[1].type == SAI2B_JOINT_TASK && ctx->h_params.task[1].full_selection) ? 2 : cert_kind(ctx);
 }
 
+// The kernel for batches with many robots inside a blending region of a 4- to 6-row MotionForceTask: tick_cert_kernel<6, S6>
+// (cert::singular_streamed); 0 when the hierarchy has no such task or is not the SVD-free kernel's
+static int sing6_kind(const sai2b_ctx* ctx) {
+	if (ctx->no_inlane_singular || ctx->no_sing6) return 0;
+	const int ck = cert_kind(ctx);
+	return ck >= 3 + 4 ? ck : 0;
+}
+
 // How many lanes a robot gets in the generic kernel (sai2b_group.hip). 16 = one DPP row per robot: the shortest
 // critical path, what the (usually short) work list behind the SVD-free kernel wants; 8 = two robots per row:
 // fewer idle lanes, better when the whole batch runs the generic kernel and fills the machine anyway.
@@ -1138,15 +1154,34 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 		ctx->otg_parity ^= 1;
 		ctx->launches += 2;
 	}
-	int fast_now = fast;
+	int fast_now = fast, cert_bits = ctx->no_inlane_singular ? 2 : 0;
 	const bool fast_wanted = fast != 0 && !ctx->introspection && do_torque && commit_sh;
-	if (fast_wanted && fast >= 3) {	 // the kernel for general hierarchies: only while it keeps most of the batch
+	if (fast_wanted) {
+		// Which first kernel, by what the last look at the counters said (every 8th tick they come back through two pinned
+		// words, never waited for): the hierarchy's own SVD-free kernel; while more than 16 384 robots leave it for the work list
+		// and the hierarchy has a 4- to 6-row MotionForceTask, the 6-row kernel with the singular branch in the lane (until
+		// fewer than 12 288 either take that branch or leave); and the generic kernel alone for 64 ticks whenever a kernel for
+		// general hierarchies keeps less than 60 % of the batch. The numbers are measured break-evens on the Panda: the
+		// in-lane 6-row branch costs every wavefront ~100 us whatever the batch, a pass over the work list ~60 us per round
+		// of 4 096 robots (16 lanes each) or ~450 us per 65 536 in its throughput form.
+		const int alt = sing6_kind(ctx);
 		if (ctx->fb_seen_pending && hipEventQuery(ctx->fb_seen_ev) == hipSuccess) {
 			ctx->fb_seen_pending = false;
-			ctx->fb_last_seen = *ctx->fb_seen;
-			if ((long long)ctx->fb_last_seen * 5 > (long long)ctx->B * 2) ctx->cert_backoff = 64;
+			const long long d = ctx->fb_seen[0], took = ctx->fb_seen[1];
+			ctx->fb_last_seen = (int)d;
+			if (ctx->sing_mode) {
+				if (d * 5 > (long long)ctx->B * 2)
+					ctx->cert_backoff = 64;
+				else if (d + took < 12288)
+					ctx->sing_mode = false;
+			} else if (alt && d > 16384) {
+				ctx->sing_mode = true;
+			} else if (fast >= 3 && d * 5 > (long long)ctx->B * 2) {
+				ctx->cert_backoff = 64;
+			}
 		}
-		if (ctx->cert_backoff > 0) {
+		if (ctx->sing_mode && alt) fast_now = alt, cert_bits |= 4;
+		if (fast_now >= 3 && ctx->cert_backoff > 0) {
 			ctx->cert_backoff--;
 			fast_now = 0;
 		}
@@ -1155,12 +1190,13 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 	ctx->last_tick_generic_only = do_torque && commit_sh && !fast_launch && !ctx->introspection;
 	if (fast_launch) ctx->fb_parity ^= 1;
 	// a long work list (thousands of robots) is throughput, not latency: two robots per DPP row, as for a whole batch
-	const bool long_list = fast_launch && fast >= 3 && ctx->fb_last_seen > 4096;  // (16 lanes: 4 robots x 1024 wavefronts in one round)
-	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast_now, ctx->baked_model ? 1 : 0, commit_sh, (with_comp ? 1 : 0) | (ctx->no_inlane_singular ? 2 : 0), do_torque, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, !fast_launch || long_list), ctx->stream))
+	const bool long_list = fast_launch && ctx->fb_last_seen > 4096;	 // (16 lanes: 4 robots x 1024 wavefronts in one round)
+	if (sai2b_launch_tick(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast_now, ctx->baked_model ? 1 : 0, commit_sh, (with_comp ? 1 : 0) | cert_bits, do_torque, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, !fast_launch || long_list), ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
 	ctx->launches++;
-	if (fast_launch && fast >= 3 && !ctx->fb_seen_pending && (ctx->cert_probe++ & 7) == 0) {
+	if (fast_launch && !ctx->fb_seen_pending && (ctx->cert_probe++ & 7) == 0) {
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->fb_seen, ctx->fb_counts + ctx->fb_parity, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->fb_seen + 1, ctx->fb_counts + 2 + ctx->fb_parity, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipEventRecord(ctx->fb_seen_ev, ctx->stream));
 		ctx->fb_seen_pending = true;
 	}
@@ -1739,7 +1775,8 @@ extern "C" int sai2b_profile_tick(sai2b_ctx* ctx, int steps, double* first_ms, d
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	int rc = upload_params(ctx);
 	if (rc) return rc;
-	const int fast = fast_kind(ctx);
+	int fast = fast_kind(ctx), cert_bits = ctx->no_inlane_singular ? 2 : 0;
+	if (ctx->sing_mode && sing6_kind(ctx)) fast = sing6_kind(ctx), cert_bits |= 4;	// (the kernel the ticks are running now)
 	const bool two = fast != 0 && !ctx->introspection;
 	// ONE event pair around `steps` back-to-back launches (an event pair per launch costs ~4 us of its own, which made
 	// the two parts add up to more than the step): first the first kernel alone, then the sequence of a tick. The
@@ -1753,9 +1790,9 @@ extern "C" int sai2b_profile_tick(sai2b_ctx* ctx, int steps, double* first_ms, d
 			HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
 			for (int s = 0; s < steps; s++) {
 				if (two) ctx->fb_parity ^= 1;
-				if (sai2b_launch_tick_part(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, ctx->baked_model ? 1 : 0, 0, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, !two), ctx->stream))
+				if (sai2b_launch_tick_part(ctx->d_params, ctx->B, ctx->introspection ? 1 : 0, fast, ctx->baked_model ? 1 : 0, 0, 1 | cert_bits, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, !two), ctx->stream))
 					return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
-				if (phase == 1 && sai2b_launch_tick_part(ctx->d_params, ctx->B, 0, fast, ctx->baked_model ? 1 : 0, 1, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, false), ctx->stream))
+				if (phase == 1 && sai2b_launch_tick_part(ctx->d_params, ctx->B, 0, fast, ctx->baked_model ? 1 : 0, 1, 1 | cert_bits, ctx->fb_counts, ctx->fb_list, ctx->fb_parity, generic_lanes(ctx, false), ctx->stream))
 					return set_error(ctx, SAI2B_RUNTIME_ERROR, "tick launch failed");
 			}
 			HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));

@@ -345,7 +345,7 @@ extern "C" int sai2b_launch_range_pass(const sai2b::DevParams* d_params, int B, 
 	return (int)hipGetLastError();
 }
 
-extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int part,
+extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int part, int with_comp_bits,
 									  int* fb_counts, int* fb_list, int parity, int group, hipStream_t stream) {
 	const dim3 grid((B + 63) / 64), block(64);
 	if (debug)
@@ -360,7 +360,7 @@ extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, i
 		hipLaunchKernelGGL((sai2b::tick_kernel<false>), grid, block, 0, stream, d_params, 1, 1, 1, (const int*)(fb_counts + parity),
 						   (const int*)fb_list);
 	else
-		launch_fast(fast, baked, grid, block, stream, d_params, 1, fb_counts, fb_list, parity);
+		launch_fast(fast, baked, grid, block, stream, d_params, fast >= 3 ? with_comp_bits : 1, fb_counts, fb_list, parity);
 	return (int)hipGetLastError();
 }
 

@@ -39,7 +39,7 @@ extern "C" int sai2b_launch_task_cert(const sai2b::DevParams* d_params, int B, i
 // one kernel of a (fast) tick on its own, for per-kernel timing: part 0 = first kernel, part 1 = the
 // generic kernel over the work list of the SVD-free one. fb_counts: 2 ints, zero before the first
 // launch; fb_list: B ints; parity alternates 0/1 between consecutive launches of the SVD-free kernel
-extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int part,
+extern "C" int sai2b_launch_tick_part(const sai2b::DevParams* d_params, int B, int debug, int fast, int baked, int part, int with_comp_bits,
 									  int* fb_counts, int* fb_list, int parity, int group, hipStream_t stream);
 // internal OTG (sai2b_otg.hip): one update of every enabled generator; (re)initialisation (modes in the kernel's comment)
 // task_mask bit t: advance task t's generator (all enabled ones: ~0)

@@ -168,6 +168,44 @@ def test_cert_kernel_backs_off_when_it_declines_most_of_the_batch():
         assert _err(g.tick(), o.tick()).max() < 1e-9
 
 
+def test_six_row_kernel_with_the_singular_branch_takes_over_when_most_of_a_big_batch_is_singular(monkeypatch):
+    """[MFT(6), JT(7)] on 32 768 UNFILTERED random poses: more than half are inside a blending region of the 6-row task (the
+    BASELINE workloads reject such poses). The headline kernel declines them; once the host has seen the count (an async
+    read-back every 8th tick) it runs tick_cert_kernel<6, S6> instead — the singular branch of a 4- to 6-row task in the
+    lane (cert::singular_streamed: eigenvalues of the 6 x 6 Gram matrix, the smallest singular triplet by inverse
+    iteration, a Householder reflector that puts the singular direction last) — and only robots with two singular
+    directions still go through the work list. Same torques (1e-9 against the oracle) and singularity bookkeeping either
+    way; SAI2B_NO_SING6=1 keeps the first route."""
+    import test_gpu_parity as tp
+
+    B = 32768
+    inp = tp._custom_inputs([("mft", {"partial": None}), ("jt", {"selection": None})], B, seed=711, singular_fraction=0.1)
+    o, g = _pair(inp)
+    monkeypatch.setenv("SAI2B_NO_SING6", "1")
+    _, h = _pair(inp)
+    monkeypatch.delenv("SAI2B_NO_SING6")
+    for c in (o, g, h):
+        ol.load_inputs(c, inp)
+    seen, seen_h = [], []
+    for tick in range(12):
+        tau_o, tau_g, tau_h = o.tick(), g.tick(), h.tick()
+        g.synchronize()  # (so that the read-back of tick 0 and 8 has certainly arrived by the next tick)
+        _, _, ro = o.get_mft_singularity(0)
+        for tau in (tau_g, tau_h):
+            e = _err(tau, tau_o)
+            assert e[ro >= 5].max() < 1e-9 and e.max() < 1e-6, (tick, e[ro >= 5].max(), e.max())
+        seen.append(g.fallback_count())
+        seen_h.append(h.fallback_count())
+        _, c1o, c2o = o.get_mft_sh_state(0)
+        for c in (g, h):
+            n, c1, c2 = c.get_mft_singularity_state(0)
+            assert np.array_equal(n, 6 - ro) and np.array_equal(c1, c1o) and np.array_equal(c2, c2o), tick
+    n_sing, n_two = int((ro < 6).sum()), int((ro < 5).sum())
+    assert n_sing > B // 3
+    assert seen[0] >= n_sing and seen_h[-1] >= n_sing  # the headline kernel declines every robot inside a region ...
+    assert n_two <= seen[-1] <= n_two + B // 100, (seen, n_two)  # ... the 6-row kernel with the branch only those with two directions
+
+
 @pytest.mark.parametrize("config", [2, 3])
 def test_six_row_instantiation_on_the_full_motion_force_task(config, monkeypatch):
     """SAI2B_PREFER_CERT=1 (read when a controller is created) sends [MFT(6)] and [MFT(6), JT(7)] — normally
