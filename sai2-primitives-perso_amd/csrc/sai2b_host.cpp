@@ -58,7 +58,7 @@ struct sai2b_ctx {
 	int* fb_seen = nullptr;		// pinned host words: [0] declined, [1] through the in-lane singular branch
 	// many robots inside a blending region of a 4- to 6-row MotionForceTask: the 6-row SVD-free kernel with the singular branch in
 	// the lane runs instead of the hierarchy's usual first kernel (launch_tick); SAI2B_NO_SING6=1 switches the mode off
-	bool sing_mode = false, no_sing6 = false;
+	bool sing_mode = false, no_sing6 = false, force_sing6 = false;
 	hipEvent_t fb_seen_ev = nullptr;
 	bool fb_seen_pending = false;
 	int cert_probe = 0, cert_backoff = 0;
@@ -686,6 +686,9 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	ctx->no_inlane_singular = nis && nis[0] == '1';
 	const char* ns6 = std::getenv("SAI2B_NO_SING6");
 	ctx->no_sing6 = ns6 && ns6[0] == '1';
+	const char* fs6 = std::getenv("SAI2B_FORCE_SING6");	 // testing aid: that kernel from the first tick on, whatever the counts
+	ctx->force_sing6 = fs6 && fs6[0] == '1';
+	ctx->sing_mode = ctx->force_sing6;
 	const char* pc = std::getenv("SAI2B_PREFER_CERT");
 	ctx->prefer_cert = pc && pc[0] == '1';
 	if (const char* gl = std::getenv("SAI2B_GENERIC_LANES")) ctx->generic_lanes_env = std::atoi(gl);
@@ -1172,7 +1175,7 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 			if (ctx->sing_mode) {
 				if (d * 5 > (long long)ctx->B * 2)
 					ctx->cert_backoff = 64;
-				else if (d + took < 12288)
+				else if (d + took < 12288 && !ctx->force_sing6)
 					ctx->sing_mode = false;
 			} else if (alt && d > 16384) {
 				ctx->sing_mode = true;

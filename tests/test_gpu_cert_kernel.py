@@ -206,6 +206,51 @@ def test_six_row_kernel_with_the_singular_branch_takes_over_when_most_of_a_big_b
     assert n_two <= seen[-1] <= n_two + B // 100, (seen, n_two)  # ... the 6-row kernel with the branch only those with two directions
 
 
+def _rows(*idx):
+    out = np.zeros((len(idx), 3))
+    for r, i in enumerate(idx):
+        out[r, i] = 1
+    return out
+
+
+@pytest.mark.parametrize("name", ["five_rows", "four_rows_rotated", "six_rows_behind_nothing", "five_rows_behind_a_joint_task"])
+def test_singular_branch_of_four_to_six_row_tasks(name, monkeypatch):
+    """cert::singular_streamed on every task size it is instantiated for (4, 5 and 6 rows), axis-aligned and rotated motion
+    spaces, first and lower levels: SAI2B_FORCE_SING6=1 runs tick_cert_kernel<6, S6> from the first tick (a batch this small
+    would never make the host choose it). Robots with at most one singular direction stay and match the oracle to 1e-9."""
+    c, s_ = np.cos(0.4), np.sin(0.4)
+    tasks = {
+        "five_rows": [("mft", {"partial": (np.eye(3), _rows(0, 1))}), ("jt", {"selection": None})],
+        "four_rows_rotated": [("mft", {"partial": (np.array([[c, s_, 0], [-s_, c, 0]]), np.array([[0, c, s_], [0, -s_, c]]))}),
+                              ("jt", {"selection": None})],
+        "six_rows_behind_nothing": [("mft", {"partial": None}), ("jt", {"selection": None})],
+        "five_rows_behind_a_joint_task": [("jt", {"selection": np.eye(7)[6:7]}), ("mft", {"partial": (np.eye(3), _rows(0, 2))}),
+                                          ("jt", {"selection": None})],
+    }[name]
+    import test_gpu_parity as tp
+
+    B = 1024 + 5
+    inp = tp._custom_inputs(tasks, B, seed=len(name), singular_fraction=0.1)
+    monkeypatch.setenv("SAI2B_FORCE_SING6", "1")
+    o, g = _pair(inp)
+    monkeypatch.delenv("SAI2B_FORCE_SING6")
+    for c_ in (o, g):
+        ol.load_inputs(c_, inp)
+    t_m = [k for k, (kind, _) in enumerate(tasks) if kind == "mft"][0]
+    rank = o.tasks[t_m].pos_range + o.tasks[t_m].ori_range
+    for tick in range(3):
+        tau_o, tau_g = o.tick(), g.tick()
+        _, _, ro = o.get_mft_singularity(t_m)
+        one = ro >= rank - 1
+        assert (ro == rank - 1).sum() > B // 50, (ro == rank - 1).sum()
+        e = _err(tau_g, tau_o)
+        assert e[one].max() < 1e-9 and e.max() < 1e-6, (tick, e[one].max(), e.max())
+        assert (~one).sum() <= g.fallback_count() <= (~one).sum() + B // 50, (g.fallback_count(), (~one).sum())
+        _, c1o, c2o = o.get_mft_sh_state(t_m)
+        n, c1, c2 = g.get_mft_singularity_state(t_m)
+        assert np.array_equal(n, rank - ro) and np.array_equal(c1, c1o) and np.array_equal(c2, c2o), tick
+
+
 @pytest.mark.parametrize("config", [2, 3])
 def test_six_row_instantiation_on_the_full_motion_force_task(config, monkeypatch):
     """SAI2B_PREFER_CERT=1 (read when a controller is created) sends [MFT(6)] and [MFT(6), JT(7)] — normally
