@@ -138,17 +138,17 @@ DI bool certify_gram_lower(const real* G, real abs2, real rel2) {
 // ---- The singular branch of the SingularityHandler in whitened coordinates (round 3) --------------------------------
 // A MotionForceTask level whose certificate fails used to send the robot to the generic kernel, which redid the whole
 // tick in projector form (the "work-list pass": half of a C4 step for 5.5 % of the robots). Everything the handler does
-// inside and around a blending region (SingularityHandler.cpp:76-160, 230-295, 313-367) has a whitened form too:
-//     Jp^T = X,  X W = Xs (one-sided Jacobi: U = W, sigma_j = |Xs_j|, V_j = Xs_j / sigma_j),  Y' = L^-1 Xs = Y W
-//     non-singular columns (positions < split):  Y'_ns = Z_ns R_ns:  Lambda_ns = (R^T R)^-1,  N_ns = L^-T (I - Z_ns Z_ns^T) L^T
-//     singular columns:                          Lambda_s = (Y'_s^T Y'_s)^-1
-//     posture task  Jpost = V_s^T N_ns N_prec:   L^-1 Jpost^T = Q' L^-1 V_s =: Yp = Z_p R_p,  Q' = Q - Z_ns Z_ns^T
-//     N N_prec = L^-T (Q' - Z_p Z_p^T) L^T
-// so the level still takes `rank` directions out of Q — Z_ns and Z_p instead of the Z of Y — and the cascade below goes on
-// in whitened form. Columns are handled by flags (ns[j] / singular otherwise), never by position: no run-time register
-// indexing. What is not handled here goes to the work list as before: a fully singular task (s_0 < s_abs_tol) and
+// inside and around a blending region (SingularityHandler.cpp:76-160, 230-295, 313-367) has a whitened form too. With the
+// thin SVD Jp = U S V^T and Y' = L^-1 Jp^T U:
+//     non-singular columns:  Y'_ns = Z_ns R_ns:  Lambda_ns = (R^T R)^-1,  N_ns = L^-T (I - Z_ns Z_ns^T) L^T
+//     singular column:       Lambda_s = 1 / (y'_s . y'_s)
+//     posture task  Jpost = v_s^T N_ns N_prec:   L^-1 Jpost^T = Q' L^-1 v_s =: y_p,  Q' = Q - Z_ns Z_ns^T,  Lambda_joint_s = 1 / (y_p . y_p)
+//     N N_prec = L^-T (Q' - y_p y_p^T / |y_p|^2) L^T
+// so the level still takes `rank` directions out of Q — Z_ns and y_p instead of the Z of Y — and the cascade below goes on
+// in whitened form. ONE singular direction (singular_streamed below says how it is found without an SVD); what is not
+// handled goes to the work list as before: two or more small singular values, a fully singular task (s_0 < s_abs_tol) and
 // enforce_handling_strategy = false (they consume fewer directions than `rank`: wrows would stop being batch-uniform),
-// a second singular MotionForceTask of the same robot, 4- to 6-row tasks (MCAP = 6: the arrays do not fit).
+// a second singular MotionForceTask of the same robot.
 
 // singularity bookkeeping of the one MotionForceTask that went through the branch, kept in registers until the robot is
 // known to finish in this kernel (flush_singular)
@@ -168,7 +168,7 @@ struct SingArgs {
 	int ti, B, b, enabled;
 	real fnorm;		 // |unit_mass_force + force_related_terms| over all six coordinates (SingularityHandler.cpp:349)
 	const real* pu;	 // M columns of the basis of range(P) in the six task coordinates (6 x 6 row-major), or NULL: the leading ones
-	const real* pose;  // this lane's LDS column behind the bounded-inertia factor (POSE_SLOTS doubles, stride 64), see singular_part
+	const real* pose;  // this lane's LDS column behind the bounded-inertia factor (POSE_SLOTS doubles, stride 64), see singular_tail
 	SingPend* sp;
 };
 
@@ -223,21 +223,6 @@ DI real masked_gram_schmidt(real* Y, const bool* on, real* R, real* rinv) {
 	}
 	return least;
 }
-// u = R^-T a over the flagged columns (rinv = 0 elsewhere), then w = Z u
-template <int M>
-DI void gs_apply(const real* Z, const real* R, const real* rinv, const real* a, real* w) {
-	real u[M];
-	UNROLL for (int j = 0; j < M; j++) {
-		real t = a[j];
-		UNROLL for (int i = 0; i < j; i++) t = fma(-R[i * M + j], u[i], t);
-		u[j] = t * rinv[j];
-	}
-	UNROLL for (int i = 0; i < N; i++) {
-		real s = 0;
-		UNROLL for (int c = 0; c < M; c++) s = fma(Z[c * N + i], u[c], s);
-		w[i] = s;
-	}
-}
 // (A^T A restricted to the flagged columns)^-1 a, A's columns given as A[j * N + i]; unflagged places return 0
 template <int M>
 DI void masked_gram_solve(const real* A, const bool* on, real* a) {
@@ -276,8 +261,7 @@ DI void add_l_times(const real* L, const real* w, real* tau) {
 	}
 }
 
-// The second half of the singular branch, shared by the two forms of the level (singular_part: tasks of 2 or 3 rows;
-// singular_streamed: 4 to 6): bookkeeping (classification by perturbed kinematics, history ring), the posture task in the
+// The second half of the singular branch (singular_streamed): bookkeeping (classification by perturbed kinematics, history ring), the posture task in the
 // singular joint direction, the joint strategy, the blend, and the posture direction out of Q. xs: the singular column of
 // Xs = Jp^T U (= sigma v), ws: the singular column of U in the task's reduced coordinates, tau_s: the sanitised and
 // clamped singular-direction torques; Q: already without the regular block's directions (Q').
@@ -463,142 +447,9 @@ DI bool singular_tail(const Fact& f, const SingArgs& sa, bool reg, real least, c
 	return least > 1e-280 && npp > 1e-280;
 }
 
-// Y, JP: what level() built (Y = L^-1 Jp^T by columns, JP = rows of Jp); fu / ff: unit mass force and force related terms in
-// the task's reduced coordinates. Adds the level's torques to tau and takes its directions out of Q. false: not handled.
-//
-// ONE singular direction (split = M - 1: every one of the 3 611 robots inside a blending region of the C4 workload), or none
-// after all (the certificate is sufficient, not necessary); two or more small singular values of a 2- or 3-row task go to the
-// work list. The columns are brought into the order [the M - 1 larger singular values | the smallest]: everything about
-// the regular block is then compile-time shaped like a level of M - 1 rows, the singular direction is one vector and its
-// Lambdas are scalars, and one flag (`reg`: the last column is regular too) is all that is left of the column masks.
-template <int M>
-DI bool singular_part(const Fact& f, const SingArgs& sa, real* Y, const real* JP, bool first, bool last, int decoupling,
-					  const real* fu, const real* ff, real* Q, real* tau) {
-	constexpr int K = M - 1;
-	const DevParams& P = *sa.P;
-	const DevTask& t = *sa.t;
-	const int B = sa.B, b = sa.b;
-	SingPend& sp = *sa.sp;
-	sp.took = 1;
-	if (sp.task >= 0) return false;	 // one per robot
-	CSTAMP_ANY(50);
-	// ---- thin SVD of Jp by one-sided Jacobi on Jp^T (SingularityHandler.cpp:78-81)
-	real X[N * M], W[M * M];
-	UNROLL for (int c = 0; c < M; c++) UNROLL for (int i = 0; i < N; i++) X[i * M + c] = JP[c * N + i];
-	hestenes<N, M>(X, W);
-	CSTAMP_ANY(51);
-	real sv[M];
-	UNROLL for (int j = 0; j < M; j++) {
-		real a = 0;
-		UNROLL for (int r = 0; r < N; r++) a = fma(X[r * M + j], X[r * M + j], a);
-		sv[j] = sqrt(a);
-	}
-	// positions in descending order (ties by index, as the oracle sorts); js: the column of the smallest singular value
-	real s0 = 0, s_last = 0, s_prev = 0;
-	int js = 0;
-	UNROLL for (int j = 0; j < M; j++) {
-		int p = 0;
-		UNROLL for (int k = 0; k < M; k++) p += (sv[k] > sv[j] || (sv[k] == sv[j] && k < j)) ? 1 : 0;
-		s0 = fmax(s0, sv[j]);
-		js = (p == M - 1) ? j : js;
-		s_last = (p == M - 1) ? sv[j] : s_last;
-		s_prev = (p == M - 2) ? sv[j] : s_prev;	 // (M = 2: position 0, the largest)
-	}
-	// ---- range split (:83-143): the first position i >= 1 with s_i / s_0 < s_max
-	if (s0 < t.s_abs_tol) return false;			   // fully singular: the task is passed through
-	if (M > 2 && s_prev / s0 < t.s_max) return false;  // two or more singular directions
-	const real icn = s_last / s0;
-	const bool reg = !(icn < t.s_max);	// not singular after all
-	const real alpha = reg ? 1.0 : fmin(fmax((icn - t.s_min) / (t.s_max - t.s_min), 0.0), 1.0);
-	if (!reg && !t.enforce) return false;
-	const bool bie = decoupling == SAI2B_BOUNDED_INERTIA_ESTIMATES, impedance = decoupling == SAI2B_IMPEDANCE;
-	// ---- columns in the order [regular block | js]: Xs (= Jp^T U), Y' = Y U, U^T F
-	real Xc[M * N], Yc[M * N], au[M], af[M], ws[M];
-	{
-		real Ur[M * M];	 // Ur[r * M + k]: component r of column k in the new order
-		UNROLL for (int k = 0; k < K; k++) UNROLL for (int r = 0; r < M; r++) Ur[r * M + k] = (js <= k) ? W[r * M + k + 1] : W[r * M + k];
-		UNROLL for (int r = 0; r < M; r++) {  // the last column: column js, by selects
-			real v = 0;
-			UNROLL for (int j = 0; j < M; j++) v = (js == j) ? W[r * M + j] : v;
-			Ur[r * M + K] = v;
-			ws[r] = v;
-		}
-		UNROLL for (int k = 0; k < M; k++) {
-			UNROLL for (int i = 0; i < N; i++) {
-				real v;
-				if (k < K) {
-					v = (js <= k) ? X[i * M + (k + 1 < M ? k + 1 : k)] : X[i * M + k];	// (k + 1 < M always holds here)
-				} else {
-					v = 0;
-					UNROLL for (int j = 0; j < M; j++) v = (js == j) ? X[i * M + j] : v;
-				}
-				Xc[k * N + i] = v;
-			}
-			real a = 0, c = 0;
-			UNROLL for (int r = 0; r < M; r++) {
-				a = fma(Ur[r * M + k], fu[r], a);
-				c = fma(Ur[r * M + k], ff[r], c);
-			}
-			au[k] = a, af[k] = c;
-			UNROLL for (int i = 0; i < N; i++) {
-				real y = 0;
-				UNROLL for (int r = 0; r < M; r++) y = fma(Y[r * N + i], Ur[r * M + k], y);
-				Yc[k * N + i] = y;
-			}
-		}
-	}
-	CSTAMP_ANY(52);
-	bool on[M];
-	UNROLL for (int k = 0; k < M; k++) on[k] = (k < K) ? true : reg;
-	// ---- Lambda_s_modified U_s^T Fu (scalar) and, with bounded inertia, Lambda_ns_modified U_ns^T Fu (:184-206)
-	real zs = 0, zn[M];
-	UNROLL for (int k = 0; k < M; k++) zn[k] = 0;
-	if (bie) {
-		real YB[M * N];
-		UNROLL for (int i = 0; i < M * N; i++) YB[i] = Xc[i];
-		solve_lb_columns<M>(f.lb, YB);
-		UNROLL for (int k = 0; k < M; k++) zn[k] = au[k];
-		masked_gram_solve<M>(YB, on, zn);
-		real g = 0;
-		UNROLL for (int i = 0; i < N; i++) g = fma(YB[K * N + i], YB[K * N + i], g);
-		zs = au[K] / g;
-	} else {
-		real g = 0;
-		UNROLL for (int i = 0; i < N; i++) g = fma(Yc[K * N + i], Yc[K * N + i], g);
-		zs = au[K] / g;	 // Lambda_s = (Jp_s M^-1 Jp_s^T)^-1 (:121)
-	}
-	CSTAMP_ANY(53);
-	// ---- singular-direction torques, sanitised and clamped (:354-365)
-	real tau_s[N];
-	UNROLL for (int i = 0; i < N; i++) {
-		real s = Xc[K * N + i] * (zs + af[K]);
-		s = (s != s) ? 0.0 : fmin(fmax(s, -P.model.effort[i]), P.model.effort[i]);
-		tau_s[i] = reg ? 0.0 : s;
-	}
-	// ---- non-singular torques (:321-322 = :307-309): direct terms through Xs, the Lambda_ns term through Z_ns
-	UNROLL for (int i = 0; i < N; i++) {
-		real s = 0;
-		UNROLL for (int k = 0; k < M; k++) s = fma(Xc[k * N + i], on[k] ? af[k] + (impedance ? au[k] : zn[k]) : 0.0, s);
-		tau[i] += s;
-	}
-	real R[M * M], rinv[M];
-	real least = masked_gram_schmidt<M>(Yc, on, R, rinv);
-	if (!bie && !impedance) {
-		real a[M], w[N];
-		UNROLL for (int k = 0; k < M; k++) a[k] = on[k] ? au[k] : 0.0;
-		gs_apply<M>(Yc, R, rinv, a, w);
-		add_l_times(f.L, w, tau);
-	}
-	// Q' = Q - Z_ns Z_ns^T
-	UNROLL for (int c = 0; c < M; c++)
-		UNROLL for (int i = 0; i < N; i++) UNROLL for (int j = 0; j <= i; j++) Q[i * N + j] = fma(-Yc[c * N + i], Yc[c * N + j], Q[i * N + j]);
-	CSTAMP_ANY(54);
-	return singular_tail<M>(f, sa, reg, least, Xc + K * N, ws, s_last, alpha, tau_s, decoupling, fu, ff, Q, tau);
-}
-
 // The cascade alone through a singular level (the range pass ahead of the trajectory generators, cert::range_tick): the
 // directions the level takes out of Q — the regular block's and the posture task's — without forces, torques or
-// bookkeeping. Same scope and same decisions as singular_part.
+// bookkeeping. Same scope and same decisions as singular_streamed (the decomposition is the one-sided Jacobi here).
 template <int M>
 DI bool singular_range(const Fact& f, const SingArgs& sa, const real* Y, const real* JP, real* Q) {
 	constexpr int K = M - 1;
@@ -668,7 +519,7 @@ DI bool singular_range(const Fact& f, const SingArgs& sa, const real* Y, const r
 	return least > 1e-280 && npp > 1e-280;
 }
 
-// the deferred bookkeeping of singular_part, for a robot that finishes in this kernel
+// the deferred bookkeeping of the singular branch, for a robot that finishes in this kernel
 DI void flush_singular(const DevParams& P, int B, int b, const SingPend& sp) {
 	if (sp.task < 0) return;
 	const DevTask& t = P.task[sp.task];
@@ -698,25 +549,17 @@ DI void flush_singular(const DevParams& P, int B, int b, const SingPend& sp) {
 	sti(IS, IS_NTYPES, B, b, sp.ntypes);
 }
 
-// One level of the cascade in reduced coordinates, M rows exactly (an instantiation per task size: the arrays of
-// a 3-row task are 3 columns wide, nothing is guarded). Jr: the task's rows (Jr[c * N + i]).
-// Task forces: Lambda va + Lambda_mod vf + vd with Lambda_mod by the decoupling type (SingularityHandler.cpp:
-// 165-206, JointTask.cpp:240-270). Adds the level's torques to tau, takes its directions out of Q. Returns the
-// certificate (true when do_cert is false: a first-level selection).
-// Order of the phases keeps few matrices alive: Y, Jp -> certificate -> the torque terms that need Jp (direct and
-// bounded-inertia ones: Jp^T x = LB (YB x), YB = LB^-1 Jp^T overwrites Jp) -> Gram-Schmidt of Y ->
-// Lambda term as L (Z R^-T a) -> downdate of Q.
-// TORQUE = false: the cascade alone (certificate and Q), for the range pass ahead of the trajectory generators.
-// ---- The singular branch for tasks of 4 to 6 rows (level_streamed) -----------------------------------------------
-// singular_part's column rotations of the 7 x 6 array Jp^T (and 36 numbers of U) do not fit beside L, Q and Jp (a first
-// version: 1.9 KB of scratch per lane, the branch 250 us). With ONE singular direction the handler needs less than an SVD:
+// ---- The singular branch, torques (every task size: level() for 2 and 3 rows, level_streamed() for 4 to 6) -------------
+// Column rotations of Jp^T with U beside it (a one-sided Jacobi: round 3's first form for 2- and 3-row tasks) are 78 numbers
+// for a 6-row task and do not fit beside L, Q and Jp (1.9 KB of scratch per lane, the branch 250 us). With ONE singular
+// direction the handler needs less than an SVD:
 // the smallest singular triplet (sigma_s, u_s, v_s = Jp^T u_s / sigma_s), the largest and the second smallest singular values
 // for its decisions, and for everything regular only the SUBSPACE orthogonal to u_s — a regular level does not care about
 // an orthogonal change of its task coordinates. So:
 //   * eigenvalues of the M x M Gram matrix G = Jp Jp^T by cyclic two-sided Jacobi, values only (21 numbers in registers);
 //     absolute accuracy eps |G|, i.e. 1e-12 relative on the smallest one inside a blending region — it only feeds decisions
 //     with thresholds (s_max) and the blending weight alpha;
-//   * u_s by inverse iteration on G - mu I (mu just below the smallest eigenvalue: three iterations), sigma_s = |Jp^T u_s|
+//   * u_s by inverse iteration on G - mu I (mu just below the smallest eigenvalue: four iterations), sigma_s = |Jp^T u_s|
 //     from Jp itself;
 //   * a Householder reflector H with H e_M = +-u_s: the rows of H^T Jp are [an orthonormal mix of the regular directions |
 //     +-sigma_s v_s^T], the singular one LAST at compile time: the regular block is level_streamed's Gram-Schmidt through the
@@ -1062,7 +905,16 @@ DI bool level_streamed(const Fact& f, const real* Jr, bool first, bool last, boo
 	return ok;
 }
 
-// SING: a level whose certificate fails goes through singular_part (MotionForceTasks of the small instantiation).
+// One level of the cascade in reduced coordinates, M rows exactly (an instantiation per task size: the arrays of
+// a 3-row task are 3 columns wide, nothing is guarded). Jr: the task's rows (Jr[c * N + i]).
+// Task forces: Lambda va + Lambda_mod vf + vd with Lambda_mod by the decoupling type (SingularityHandler.cpp:
+// 165-206, JointTask.cpp:240-270). Adds the level's torques to tau, takes its directions out of Q. Returns the
+// certificate (true when do_cert is false: a first-level selection).
+// Order of the phases keeps few matrices alive: Y, Jp -> certificate -> the torque terms that need Jp (direct and
+// bounded-inertia ones: Jp^T x = LB (YB x), YB = LB^-1 Jp^T overwrites Jp) -> Gram-Schmidt of Y ->
+// Lambda term as L (Z R^-T a) -> downdate of Q.
+// TORQUE = false: the cascade alone (certificate and Q), for the range pass ahead of the trajectory generators.
+// SING: a MotionForceTask level whose certificate fails goes through singular_streamed (torques) / singular_range (the range pass).
 template <int M, bool TORQUE = true, bool SING = false>
 DI bool level(const Fact& f, const real* Jr, bool first, bool last, bool do_cert, real abs2, real rel2, int decoupling,
 			  bool has_va, const real* va, const real* vf, const real* vd, real* Q, real* tau, const SingArgs* sa = nullptr) {
@@ -1103,8 +955,11 @@ DI bool level(const Fact& f, const real* Jr, bool first, bool last, bool do_cert
 	}
 	if constexpr (SING && M >= 2) {	 // (a one-row task has no blending region: it is regular or fully singular)
 		if (sa->enabled && !ok) {
+			// (the form written for 4- to 6-row tasks — Gram eigenvalues, inverse iteration, Householder — is also the faster
+			// one for 2 and 3 rows: 74.5 against 76.0 us on C4 in a same-box A/B with round 3's first form, column rotations
+			// of Jp^T with the columns re-ordered afterwards; same 5e-14 against the oracle)
 			if constexpr (TORQUE)
-				return singular_part<M>(f, *sa, Y, JP, first, last, decoupling, vf, vd, Q, tau);
+				return singular_streamed<M>(f, *sa, JP, decoupling, vf, vd, Q, tau);
 			else
 				return singular_range<M>(f, *sa, Y, JP, Q);
 		}
@@ -1446,7 +1301,7 @@ constexpr int TASK_FREE = N + (PEND_SLOTS - N - 12);
 constexpr int TASK_EXTRA = (N * (N + 1) / 2 > TASK_FREE) ? N * (N + 1) / 2 - TASK_FREE : 0;
 DI int q0_slot(int k) { return k < N ? k : (k < TASK_FREE ? k + 12 : LDS_SLOTS + (k - TASK_FREE)); }
 
-// sp: the bookkeeping of a MotionForceTask that went through singular_part (the caller flushes it with the rest);
+// sp: the bookkeeping of a MotionForceTask that went through the singular branch (the caller flushes it with the rest);
 // NULL: such robots go to the work list (MCAP = 6, the task-level calls, SAI2B_NO_INLANE_SINGULAR)
 // S6: the instantiation whose 4- to 6-row MotionForceTasks have the singular branch too (singular_streamed). A kernel of its
 // own, chosen by the host while many robots are inside a blending region (sai2b_host.cpp: launch_tick): the branch's
@@ -1588,7 +1443,7 @@ DI bool tick(const DevParams& P, const MD& md, int B, int b, bool with_comp, rea
 			const real zero[6] = {0, 0, 0, 0, 0, 0};
 			SingArgs sa;
 			SingPend none;
-			none.task = 0;	// "taken": singular_part declines
+			none.task = 0;	// "taken": the singular branch declines
 			sa.P = &P, sa.t = &t, sa.ti = ti, sa.B = B, sa.b = b, sa.enabled = inlane, sa.pu = nullptr, sa.sp = inlane ? sp : &none, sa.pose = (TASK || MCAP > 3) ? nullptr : pend + LDS_SLOTS * 64;
 			const int task_before = sa.sp->task;
 			{
