@@ -188,8 +188,15 @@ def main():
     first = window()
     (w0,) = pkg.sharding.max_over_ranks([first[0]], device=red_device)
     n_windows = 1 if w0 >= 0.05 else int(min(400, max(9, np.ceil(0.05 / max(w0, 1e-6)))))
+    # Between SHORT windows (< 10 ms) the device would sit idle while the host goes through two barriers: a duty cycle of
+    # ~80 % that the clock governor answers with a lower clock than a controller running back to back sees (measured:
+    # --steps 20 read 5.5 % below --steps 200 on the same box). So ~3 ms of UNTIMED ticks are queued behind each short
+    # window before its closing barrier — warm-up in the sense of the contract, never inside a timed region.
+    keep_warm = 0 if w0 >= 0.01 else int(np.ceil(3e-3 / max(w0 / args.steps, 1e-6)))
     walls, evs = [], []
     for _ in range(n_windows):
+        for _k in range(keep_warm):
+            ctrl.tick(want_output=False)
         w, e = window()
         walls.append(w)
         evs.append(e)
@@ -220,7 +227,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "timed_windows": {"count": n_windows, "reported": "median", "ms_per_step_min": float(walls.min()) / args.steps * 1e3,
+            "timed_windows": {"count": n_windows, "reported": "median", "untimed_ticks_between_windows": keep_warm,
+                              "ms_per_step_min": float(walls.min()) / args.steps * 1e3,
                               "ms_per_step_max": float(walls.max()) / args.steps * 1e3},
             "higher_is_better": True,
             "scaling": "weak",
