@@ -186,13 +186,28 @@ DI void load_goals(const DevTask& t, bool cart, int n, int B, int b, Goals& G) {
 //   PLAN    the goal changed (setGoal... will touch the input) or the input differs from the stored
 //           one (ruckig.hpp:194): the full update with the planner, done by otg_plan_kernel.
 enum { IDLE = 0, SAMPLE = 1, PLAN = 2 };
-DI int classify(const DevTask& t, bool cart, int n, int B, int b, Gen& g, Goals& G, bool goals_clean, bool& in_sync) {
+// head_loaded: the wrapper's targets and flags (load_head) are in g; a robot that only samples a trajectory that is still
+// running needs none of them, and they are fetched when its trajectory ends (sample_lane)
+DI int classify(const DevTask& t, bool cart, int n, int B, int b, Gen& g, Goals& G, bool goals_clean, bool& in_sync, bool& head_loaded) {
 	const real* S = t.otg_state;
 	in_sync = false;
+	head_loaded = false;
 	// The host has not touched this task's goals (nor its OTG configuration) since the previous
-	// update: for a robot whose goal is reached setGoal...() is the same no-op as last time, so its
-	// flag alone decides (1 row instead of ~35)
-	if (goals_clean && ldflag(S, OTG_GOAL_REACHED, B, b) != 0) return IDLE;
+	// update: setGoal...() is the same no-op as last time. For a robot whose goal is reached its flag alone
+	// decides (1 row instead of ~35); for a robot on its way, in sync with its stored input, the goal rows and the
+	// stored targets they would be compared with are not read at all (round 3: 28 of ~150 rows of a JointTask's
+	// generator, 42 of ~165 of a MotionForceTask's, per tick)
+	if (goals_clean) {
+		if (ldflag(S, OTG_GOAL_REACHED, B, b) != 0) return IDLE;
+		if (ldflag(S, OTG_IN_SYNC, B, b) != 0 && ldflag(S, OTG_TARGET_SET, B, b) == (cart ? 3 : 1)) {
+			in_sync = true;
+			g.goal_reached = 0;
+			g.ci_init = ldflag(S, OTG_CI_INIT, B, b);
+			g.ci_epoch = ld(S, OTG_CI_EPOCH, B, b);
+			return (g.ci_epoch != t.otg_epoch || !g.ci_init) ? PLAN : SAMPLE;	// inputs equal by definition
+		}
+	}
+	head_loaded = true;
 	load_head(S, n, cart, B, b, g);
 	load_goals(t, cart, n, B, b, G);
 	bool unchanged;
@@ -282,7 +297,7 @@ DI int sample_jerk(const DevTask& t, bool cart, int n, int B, int b, Gen& g) {
 
 // JERK: the instantiation of otg_kernel launched while some task's generator is jerk-limited; the other one compiles
 // exactly as it did before that mode existed (its registers and scratch are what the all-moving case is bound by)
-template <bool JERK> DI void sample_lane(const DevTask& t, bool cart, int n, int B, int b, Gen& g, bool in_sync) {
+template <bool JERK> DI void sample_lane(const DevTask& t, bool cart, int n, int B, int b, Gen& g, bool in_sync, bool head_loaded) {
 	real* S = t.otg_state;
 	bool done = false;
 	if constexpr (JERK) {
@@ -301,6 +316,11 @@ template <bool JERK> DI void sample_lane(const DevTask& t, bool cart, int n, int
 	} else {
 		// Finished: Ruckig's stored input follows the output, the wrapper's input stays where it was
 		// (OTG_joints.cpp:125-135): back to explicit rows
+		if (!head_loaded) {
+			const int res = g.result;  // (load_head reads the stored result of the previous update)
+			load_head(S, n, cart, B, b, g);
+			g.result = res;
+		}
 		if (in_sync) {	// where it was = the previous output, still in memory
 			load7(S, OTG_OUT, n, B, b, g.in.cp);
 			load7(S, OTG_OUT + MD, n, B, b, g.in.cv);
@@ -633,9 +653,9 @@ __global__ __launch_bounds__(64) void otg_kernel(const DevParams* __restrict__ P
 		if (live && !(tk.otg_gated && ld(tk.otg_state, OTG_ACTIVE, B, b) == 0.0)) {
 			Gen g;
 			Goals G;
-			bool in_sync;
-			cls = classify(tk, cart, tk.otg_n, B, b, g, G, ((clean_mask >> t) & 1) != 0, in_sync);
-			if (cls == SAMPLE) sample_lane<JERK>(tk, cart, tk.otg_n, B, b, g, in_sync);
+			bool in_sync, head_loaded;
+			cls = classify(tk, cart, tk.otg_n, B, b, g, G, ((clean_mask >> t) & 1) != 0, in_sync, head_loaded);
+			if (cls == SAMPLE) sample_lane<JERK>(tk, cart, tk.otg_n, B, b, g, in_sync, head_loaded);
 		}
 		const unsigned long long mask = __ballot(cls == PLAN);
 		if (mask) {
