@@ -23,14 +23,34 @@ def _solve_lower(L, x):
     return np.linalg.solve(L, x)
 
 
-def _whitened_singular_mft(o, cfg, model, b, q, dq, M, J, Fu, Ff, sv, alpha, c1, c2, decoupling):
+def _whitened_singular_mft(o, cfg, model, b, q, dq, M, J, Fu, Ff, sv, alpha, c1, c2, decoupling, householder=False):
     """torques and N N_prec of a first-level position task (rows 0..2 of J) with ONE singular direction, as the kernel forms them"""
     L = np.linalg.cholesky(M)
     Jp = J[:3]  # first level: N_prec = I
     X = Jp.T
     U, S, Vt = np.linalg.svd(Jp, full_matrices=False)
     assert np.allclose(S, sv[:3], rtol=1e-9)
-    Xs = X @ U  # columns sigma_j v_j
+    if householder:
+        # the kernel's route (cert::singular_streamed): no SVD — the smallest eigenpair of the Gram matrix Jp Jp^T by inverse
+        # iteration, sigma_s = |Jp^T u_s|, and a Householder reflector H with H e_3 = +-u_s; the rows of H^T Jp are [an
+        # orthonormal mix of the regular directions | +-sigma_s v_s^T]: a regular level does not care which orthonormal
+        # basis of the regular subspace it is given
+        G = Jp @ Jp.T
+        lam = np.linalg.eigvalsh(G)
+        us = np.array([1.0, 1.37, 1.74])
+        A = G - (lam[0] * (1 - 1e-6) - 1e-14 * lam[-1]) * np.eye(3)
+        for _ in range(4):
+            us = np.linalg.solve(A, us)
+            us /= np.linalg.norm(us)
+        sg = -1.0 if us[2] > 0 else 1.0
+        w = us * sg - np.array([0, 0, 1.0])
+        H = np.eye(3) - 2 * np.outer(w, w) / (w @ w)
+        U = H.copy()
+        U[:, 2] *= sg  # last column = u_s
+        assert abs(np.linalg.norm(Jp.T @ us) - sv[2]) < 1e-11 * sv[0]
+        Vt = np.zeros((3, N))
+        Vt[2] = Jp.T @ us / np.linalg.norm(Jp.T @ us)
+    Xs = X @ U  # columns sigma_j v_j (SVD) / an orthonormal mix of the regular ones and sigma_s v_s (Householder)
     Yp = _solve_lower(L, Xs)
     fu, ff = U.T @ Fu[:3], U.T @ Ff[:3]
     ns, s = [0, 1], 2
@@ -93,8 +113,9 @@ def _whitened_singular_mft(o, cfg, model, b, q, dq, M, J, Fu, Ff, sv, alpha, c1,
     return tau, Linv.T @ Q2 @ L.T, Q2, L
 
 
+@pytest.mark.parametrize("householder", [False, True])
 @pytest.mark.parametrize("decoupling", [0, 1, 2])
-def test_singular_branch_in_whitened_coordinates_equals_the_projector_form(decoupling):
+def test_singular_branch_in_whitened_coordinates_equals_the_projector_form(decoupling, householder):
     B = 768
     inp = pkg.workloads.make_inputs(4, B=B, seed=4600 + decoupling)
     go = ol.task_configs(inp["tasks"])
@@ -121,7 +142,7 @@ def test_singular_branch_in_whitened_coordinates_equals_the_projector_form(decou
         M = Mall[:, b].reshape(N, N)
         J = Jall[:, b].reshape(6, N)
         tau, Ntot, Q2, L = _whitened_singular_mft(o, go[0], model, b, q[:, b], dq[:, b], M, J, Fu[:, b], Ff[:, b], sv[:, b], alpha[b], c1[b],
-                                               c2[b], decoupling)
+                                               c2[b], decoupling, householder)
         worst_t = max(worst_t, np.abs(tau - tau_o[:, b]).max() / max(1.0, np.abs(tau_o[:, b]).max()))
         worst_n = max(worst_n, np.abs(Ntot - N0[:, b].reshape(N, N)).max())
         # the cascade goes on in whitened form: the partial JointTask (joints 0 and 6) behind it, Y = Q2 L^-1 S^T
