@@ -79,9 +79,22 @@ def _configs(make, tasks, opts, otg, frames=None):
     return cfgs
 
 
-# SAI2B_FUZZ_SEEDS=<n> widens the sweep for an exploratory run (2 000 seeds of each test were run clean when this was written)
+# SAI2B_FUZZ_SEEDS=<n> widens the sweep for an exploratory run (4 000 seeds of each of the five tests were run clean at the end of round 3)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SAI2B_FUZZ_SEEDS", "48"))))
 def test_random_configuration_closed_loop(seed):
+    _closed_loop(seed)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SAI2B_FUZZ_SEEDS", "24"))))
+def test_random_configuration_closed_loop_through_the_six_row_singular_kernel(seed, monkeypatch):
+    """the same sweep with SAI2B_FORCE_SING6=1: hierarchies with a 4- to 6-row MotionForceTask (and [full MFT(, JT)], normally the
+    headline kernel's) run tick_cert_kernel<6, S6> — the singular branch of such tasks in the lane — from the first tick, which
+    batches of this size would never make the host choose"""
+    monkeypatch.setenv("SAI2B_FORCE_SING6", "1")
+    _closed_loop(seed)
+
+
+def _closed_loop(seed):
     rng = np.random.default_rng(9000 + seed)
     name = sorted(SHAPES)[seed % len(SHAPES)]
     tasks = SHAPES[name]
