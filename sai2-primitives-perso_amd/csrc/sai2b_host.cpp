@@ -1161,12 +1161,13 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 	const bool fast_wanted = fast != 0 && !ctx->introspection && do_torque && commit_sh;
 	if (fast_wanted) {
 		// Which first kernel, by what the last look at the counters said (every 8th tick they come back through two pinned
-		// words, never waited for): the hierarchy's own SVD-free kernel; while more than 16 384 robots leave it for the work list
+		// words, never waited for): the hierarchy's own SVD-free kernel; while more than 20 480 robots leave it for the work list
 		// and the hierarchy has a 4- to 6-row MotionForceTask, the 6-row kernel with the singular branch in the lane (until
-		// fewer than 12 288 either take that branch or leave); and the generic kernel alone for 64 ticks whenever a kernel for
-		// general hierarchies keeps less than 60 % of the batch. The numbers are measured break-evens on the Panda: the
-		// in-lane 6-row branch costs every wavefront ~100 us whatever the batch, a pass over the work list ~60 us per round
-		// of 4 096 robots (16 lanes each) or ~450 us per 65 536 in its throughput form.
+		// fewer than 15 360 either take that branch or leave); and the generic kernel alone for 64 ticks whenever a kernel for
+		// general hierarchies keeps less than 60 % of the batch. The numbers are the measured break-even on the Panda
+		// (scripts/micro/sing6_crossover.py: 65 536 robots, 14 890 declined: 173 us against 215 us with the 6-row kernel;
+		// 22 382 declined: 238 against 195): the in-lane 6-row branch costs every wavefront ~100 us whatever the batch, a pass
+		// over the work list ~60 us per round of 4 096 robots (16 lanes each) or ~450 us per 65 536 in its throughput form.
 		const int alt = sing6_kind(ctx);
 		if (ctx->fb_seen_pending && hipEventQuery(ctx->fb_seen_ev) == hipSuccess) {
 			ctx->fb_seen_pending = false;
@@ -1175,9 +1176,9 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 			if (ctx->sing_mode) {
 				if (d * 5 > (long long)ctx->B * 2)
 					ctx->cert_backoff = 64;
-				else if (d + took < 12288 && !ctx->force_sing6)
+				else if (d + took < 15360 && !ctx->force_sing6)
 					ctx->sing_mode = false;
-			} else if (alt && d > 16384) {
+			} else if (alt && d > 20480) {
 				ctx->sing_mode = true;
 			} else if (fast >= 3 && d * 5 > (long long)ctx->B * 2) {
 				ctx->cert_backoff = 64;
