@@ -169,7 +169,7 @@ def test_cert_kernel_backs_off_when_it_declines_most_of_the_batch():
 
 
 def test_six_row_kernel_with_the_singular_branch_takes_over_when_most_of_a_big_batch_is_singular(monkeypatch):
-    """[MFT(6), JT(7)] on 32 768 UNFILTERED random poses: more than half are inside a blending region of the 6-row task (the
+    """[MFT(6), JT(7)] on 49 152 UNFILTERED random poses: more than half are inside a blending region of the 6-row task (the
     BASELINE workloads reject such poses). The headline kernel declines them; once the host has seen the count (an async
     read-back every 8th tick) it runs tick_cert_kernel<6, S6> instead — the singular branch of a 4- to 6-row task in the
     lane (cert::singular_streamed: eigenvalues of the 6 x 6 Gram matrix, the smallest singular triplet by inverse
@@ -178,7 +178,7 @@ def test_six_row_kernel_with_the_singular_branch_takes_over_when_most_of_a_big_b
     way; SAI2B_NO_SING6=1 keeps the first route."""
     import test_gpu_parity as tp
 
-    B = 32768
+    B = 49152  # (the host switches above 20 480 declined robots)
     inp = tp._custom_inputs([("mft", {"partial": None}), ("jt", {"selection": None})], B, seed=711, singular_fraction=0.1)
     o, g = _pair(inp)
     monkeypatch.setenv("SAI2B_NO_SING6", "1")
