@@ -84,18 +84,24 @@ def test_cert_kernel_c4_hierarchy_keeps_regular_and_singular_robots(decoupling, 
             assert np.array_equal(n > 0, sing) and np.array_equal(c1, c1o) and np.array_equal(c2, c2o)
 
 
-def test_singular_branch_in_the_kernel_follows_robots_in_and_out_of_the_region():
-    """robots of the C4 hierarchy carried across the boundary of the blending region and back (the elbow joint swept
-    through its extended pose over 40 ticks): entering conditions, the history ring (one bit per tick, 20 deep here),
-    the switch between the type-1 and type-2 joint strategies and the clearing on the way out all happen in
-    cert::singular_part / flush_singular — torques and bookkeeping must follow the oracle tick by tick."""
+@pytest.mark.parametrize("config", [4, 3])
+def test_singular_branch_in_the_kernel_follows_robots_in_and_out_of_the_region(config, monkeypatch):
+    """robots carried across the boundary of the blending region and back (the elbow joint swept through its extended pose
+    over 40 ticks): entering conditions, the history ring (one bit per tick, 20 deep here), the switch between the type-1
+    and type-2 joint strategies and the clearing on the way out all happen in cert::singular_tail / flush_singular —
+    torques and bookkeeping must follow the oracle tick by tick. The C4 hierarchy (3-row task, tick_cert_kernel<3>) and
+    the headline hierarchy through the 6-row kernel with the branch (SAI2B_FORCE_SING6=1)."""
     B = 256
-    inp = pkg.workloads.make_inputs(4, B=B, seed=4400)
+    inp = pkg.workloads.make_inputs(config, B=B, seed=4400)
     go, gg = ol.task_configs(inp["tasks"]), pkg.task_configs(inp["tasks"])
     for cfgs in (go, gg):
         cfgs[0].sh_buffer_size = 20
+    rank = 3 if config == 4 else 6
     o = ol.Oracle(ol.panda_model(), go, B, threads=8)
+    if config == 3:
+        monkeypatch.setenv("SAI2B_FORCE_SING6", "1")
     g = pkg.Controller(pkg.panda_model(), gg, B)
+    monkeypatch.delenv("SAI2B_FORCE_SING6", raising=False)
     for c in (o, g):
         ol.load_inputs(c, inp)
     rng = np.random.default_rng(5)
@@ -110,14 +116,17 @@ def test_singular_branch_in_the_kernel_follows_robots_in_and_out_of_the_region()
         g.set_state(q, dq)
         tau_o, tau_g = o.tick(), g.tick()
         _, _, ro = o.get_mft_singularity(0)
-        seen_in += int((ro < 3).sum())
-        seen_out += int((ro == 3).sum())
-        assert _err(tau_g, tau_o).max() < 1e-9, (tick, _err(tau_g, tau_o).max())
-        assert g.fallback_count() <= 2
+        seen_in += int((ro < rank).sum())
+        seen_out += int((ro == rank).sum())
+        one = ro >= rank - 1  # (two singular directions at once: the generic kernel's, 1e-6 as everywhere)
+        e = _err(tau_g, tau_o)
+        assert e[one].max() < 1e-9 and e.max() < 1e-6, (tick, e[one].max(), e.max())
+        assert g.fallback_count() <= (~one).sum() + 2
         _, c1o, c2o = o.get_mft_sh_state(0)
         n, c1, c2 = g.get_mft_singularity_state(0)
-        assert np.array_equal(c1, c1o) and np.array_equal(c2, c2o) and np.array_equal(n > 0, ro < 3), tick
-    assert seen_in > 20 * B // 10 and seen_out > 20 * B // 10, (seen_in, seen_out)
+        assert np.array_equal(c1, c1o) and np.array_equal(c2, c2o) and np.array_equal(n > 0, ro < rank), tick
+    # (the 6-row task is inside a region for most of this sweep; the 3-row task for about half of it)
+    assert seen_in > 20 * B // 10 and seen_out > (20 * B // 10 if config == 4 else B), (seen_in, seen_out)
 
 
 @pytest.mark.parametrize("name", ["c4", "partial_mft_mixed", "jt_first"])
