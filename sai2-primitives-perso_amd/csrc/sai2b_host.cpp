@@ -80,6 +80,15 @@ struct sai2b_ctx {
 	// bit t set: task t's goals may have changed since the last OTG update (setters, reinitialize, config
 	// updates); goals_exposed: the caller holds the device pointer of some goals buffer, so always assume it
 	unsigned goals_dirty = ~0u;
+	// Every generator idle (goal reached, goals untouched since): an update is a no-op for every robot, and stays one until the
+	// host touches a goal or a generator's configuration — the generator kernels are not launched at all then. Known from the
+	// count of non-idle robots otg_kernel leaves behind (read back asynchronously every 8th tick, never waited for) of a tick
+	// launched with the goals as they still are (goals_epoch). SAI2B_NO_OTG_IDLE_SKIP=1 switches it off.
+	bool otg_all_idle = false, no_otg_idle_skip = false, otg_seen_pending = false;
+	unsigned long long goals_epoch = 0, otg_obs_epoch = 0;
+	int* otg_busy_seen = nullptr;  // pinned host word
+	hipEvent_t otg_seen_ev = nullptr;
+	unsigned otg_probe = 0;
 	bool goals_exposed = false;
 	sai2b_robot_model model;
 	sai2b_task_config cfg[SAI2B_MAX_TASKS];
@@ -684,6 +693,8 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	ctx->no_task_cert = ntc && ntc[0] == '1';
 	const char* nis = std::getenv("SAI2B_NO_INLANE_SINGULAR");
 	ctx->no_inlane_singular = nis && nis[0] == '1';
+	const char* nois = std::getenv("SAI2B_NO_OTG_IDLE_SKIP");
+	ctx->no_otg_idle_skip = nois && nois[0] == '1';
 	const char* ns6 = std::getenv("SAI2B_NO_SING6");
 	ctx->no_sing6 = ns6 && ns6[0] == '1';
 	const char* fs6 = std::getenv("SAI2B_FORCE_SING6");	 // testing aid: that kernel from the first tick on, whatever the counts
@@ -722,7 +733,10 @@ static int create_impl(sai2b_ctx* ctx, const sai2b_robot_model* model, const sai
 	HIP_TRY(ctx, hipHostMalloc((void**)&ctx->fb_seen, 2 * sizeof(int), hipHostMallocDefault));
 	ctx->fb_seen[0] = ctx->fb_seen[1] = 0;
 	HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fb_seen_ev, hipEventDisableTiming));
-	if ((rc = dev_alloc(ctx, &ctx->otg_counts, 2 * SAI2B_MAX_TASKS))) return rc;
+	if ((rc = dev_alloc(ctx, &ctx->otg_counts, 2 * SAI2B_MAX_TASKS + 2))) return rc;  // (+ 2: non-idle robots of a tick, alternating)
+	HIP_TRY(ctx, hipHostMalloc((void**)&ctx->otg_busy_seen, sizeof(int), hipHostMallocDefault));
+	*ctx->otg_busy_seen = 1;
+	HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->otg_seen_ev, hipEventDisableTiming));
 	if ((rc = dev_alloc(ctx, &ctx->otg_list, SAI2B_MAX_TASKS * Bs))) return rc;
 	for (int t = 0; t < n_tasks; t++) {
 		ctx->cfg[t] = tasks[t];
@@ -794,6 +808,8 @@ extern "C" void sai2b_destroy(sai2b_ctx* ctx) {
 	if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
 	if (ctx->ev_out) (void)hipEventDestroy(ctx->ev_out);
 	if (ctx->fb_seen_ev) (void)hipEventDestroy(ctx->fb_seen_ev);
+	if (ctx->otg_seen_ev) (void)hipEventDestroy(ctx->otg_seen_ev);
+	if (ctx->otg_busy_seen) (void)hipHostFree(ctx->otg_busy_seen);
 	if (ctx->fb_seen) (void)hipHostFree(ctx->fb_seen);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -867,6 +883,7 @@ extern "C" int sai2b_update_task_config(sai2b_ctx* ctx, int task, const sai2b_ta
 	d.law_goals = d.otg_on ? (d.otg_out_is_desired ? d.otg_state + (size_t)sai2b::OTG_OUT * ctx->B : d.otg_desired) : d.goals;
 	ctx->params_dirty = true;
 	ctx->goals_dirty |= 1u << task;
+	ctx->goals_epoch++, ctx->otg_all_idle = false;
 	// enableInternalOtgAccelerationLimited (JointTask.cpp:360-381, MotionForceTask.cpp:511-523) is
 	// applied when the OTG fields change: new limits make every moving robot re-plan
 	// (InputParameter::operator!=, input_parameter.hpp:362-394); a generator that was off is
@@ -969,6 +986,7 @@ extern "C" int sai2b_set_mft_goals(sai2b_ctx* ctx, int task, const double* pos, 
 	double* G = ctx->h_params.task[task].goals;
 	const size_t B = ctx->B;
 	ctx->goals_dirty |= 1u << task;
+	ctx->goals_epoch++, ctx->otg_all_idle = false;
 	if ((rc = copy_rows(ctx, G, pos, 3, on_device))) return rc;
 	if ((rc = copy_rows(ctx, G + 3 * B, rot, 9, on_device))) return rc;
 	if ((rc = copy_rows(ctx, G + 12 * B, lin_vel, 3, on_device))) return rc;
@@ -1003,6 +1021,7 @@ extern "C" int sai2b_set_jt_goals(sai2b_ctx* ctx, int task, const double* q_goal
 	double* G = ctx->h_params.task[task].goals;
 	const size_t B = ctx->B, k0 = ctx->cfg[task].task_dof;
 	ctx->goals_dirty |= 1u << task;
+	ctx->goals_epoch++, ctx->otg_all_idle = false;
 	int rc;
 	if ((rc = copy_rows(ctx, G, q_goal, k0, on_device))) return rc;
 	if ((rc = copy_rows(ctx, G + k0 * B, dq_goal, k0, on_device))) return rc;
@@ -1019,6 +1038,7 @@ extern "C" int sai2b_reinitialize(sai2b_ctx* ctx) {
 	if (sai2b_launch_otg_reinit(ctx->d_params, ctx->B, -1, 0, ctx->q, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG reinit launch failed");
 	ctx->goals_dirty = ~0u;
+	ctx->goals_epoch++, ctx->otg_all_idle = false;
 	ctx->launches += 2;
 	ctx->models_fresh = false;
 	ctx->q_is_pose = true;	// reInitializeTask reads the pose of the current state
@@ -1150,12 +1170,26 @@ static int launch_tick(sai2b_ctx* ctx, int commit_sh, int with_comp, int do_torq
 		}
 	}
 	if (do_torque && any_otg(ctx)) {  // the generators advance once per torque computation, before the law
-		// (a gated task keeps reading its goals: a robot skipped while they changed must see them later)
-		const int clean_mask = ctx->goals_exposed ? 0 : (int)(~ctx->goals_dirty & ~gated & ((1u << SAI2B_MAX_TASKS) - 1u));
-		ctx->goals_dirty = 0;
-		if (sai2b_launch_otg(ctx->d_params, ctx->B, ctx->otg_counts, ctx->otg_list, ctx->otg_parity, clean_mask, ~0, jerk_mask(ctx), ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG launch failed");
-		ctx->otg_parity ^= 1;
-		ctx->launches += 2;
+		if (ctx->otg_seen_pending && hipEventQuery(ctx->otg_seen_ev) == hipSuccess) {
+			ctx->otg_seen_pending = false;
+			if (*ctx->otg_busy_seen == 0 && ctx->otg_obs_epoch == ctx->goals_epoch) ctx->otg_all_idle = true;
+		}
+		// (see otg_all_idle: exact, not a heuristic — an idle generator's update neither reads nor writes anything)
+		const bool idle_skip = ctx->otg_all_idle && !gated && !ctx->goals_exposed && ctx->goals_dirty == 0 && !ctx->no_otg_idle_skip;
+		if (!idle_skip) {
+			// (a gated task keeps reading its goals: a robot skipped while they changed must see them later)
+			const int clean_mask = ctx->goals_exposed ? 0 : (int)(~ctx->goals_dirty & ~gated & ((1u << SAI2B_MAX_TASKS) - 1u));
+			ctx->goals_dirty = 0;
+			if (sai2b_launch_otg(ctx->d_params, ctx->B, ctx->otg_counts, ctx->otg_list, ctx->otg_parity, clean_mask, ~0, jerk_mask(ctx), ctx->stream)) return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG launch failed");
+			if (!gated && !ctx->goals_exposed && !ctx->otg_seen_pending && (ctx->otg_probe++ & 7) == 0) {
+				HIP_TRY(ctx, hipMemcpyAsync(ctx->otg_busy_seen, ctx->otg_counts + 2 * SAI2B_MAX_TASKS + ctx->otg_parity, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+				HIP_TRY(ctx, hipEventRecord(ctx->otg_seen_ev, ctx->stream));
+				ctx->otg_seen_pending = true;
+				ctx->otg_obs_epoch = ctx->goals_epoch;
+			}
+			ctx->otg_parity ^= 1;
+			ctx->launches += 2;
+		}
 	}
 	int fast_now = fast, cert_bits = ctx->no_inlane_singular ? 2 : 0;
 	const bool fast_wanted = fast != 0 && !ctx->introspection && do_torque && commit_sh;
@@ -1417,6 +1451,7 @@ extern "C" int sai2b_task_reinitialize(sai2b_ctx* ctx, int task) {
 	if (sai2b_launch_otg_reinit(ctx->d_params, ctx->B, task, 0, ctx->q, ctx->stream))
 		return set_error(ctx, SAI2B_RUNTIME_ERROR, "OTG reinit launch failed");
 	ctx->goals_dirty |= 1u << task;
+	ctx->goals_epoch++, ctx->otg_all_idle = false;
 	ctx->launches += 2;
 	ctx->models_fresh = false;
 	ctx->tio[task].model_fresh = false;

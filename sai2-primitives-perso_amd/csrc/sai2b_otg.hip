@@ -643,6 +643,7 @@ __global__ __launch_bounds__(64) void otg_kernel(const DevParams* __restrict__ P
 	const int B = P.B;
 	const int b = blockIdx.x * 64 + threadIdx.x;
 	const bool live = b < B;
+	bool busy = false;	// some generator of this robot is not idle (the host stops launching these kernels when none is: sai2b_host.cpp)
 #pragma unroll 1
 	for (int t = 0; t < P.n_tasks; t++) {
 		const DevTask& tk = P.task[t];
@@ -656,6 +657,7 @@ __global__ __launch_bounds__(64) void otg_kernel(const DevParams* __restrict__ P
 			bool in_sync, head_loaded;
 			cls = classify(tk, cart, tk.otg_n, B, b, g, G, ((clean_mask >> t) & 1) != 0, in_sync, head_loaded);
 			if (cls == SAMPLE) sample_lane<JERK>(tk, cart, tk.otg_n, B, b, g, in_sync, head_loaded);
+			busy = busy || cls != IDLE;
 		}
 		const unsigned long long mask = __ballot(cls == PLAN);
 		if (mask) {
@@ -668,6 +670,10 @@ __global__ __launch_bounds__(64) void otg_kernel(const DevParams* __restrict__ P
 			}
 		}
 	}
+	{
+		const unsigned long long m = __ballot(busy);
+		if (m && (threadIdx.x & 63) == 0) atomicAdd(&counts[2 * SAI2B_MAX_TASKS + parity], __popcll(m));
+	}
 }
 
 // The robots otg_kernel left over (goal changed / input differs), compacted: group i (8 lanes, one DoF
@@ -677,6 +683,7 @@ __global__ __launch_bounds__(64) void otg_plan_kernel(const DevParams* __restric
 	const DevParams& P = *Pp;
 	const int B = P.B;
 	if (blockIdx.x == 0 && threadIdx.x < SAI2B_MAX_TASKS) ((gint*)counts)[(1 - parity) * SAI2B_MAX_TASKS + threadIdx.x] = 0;  // next tick's counters
+	if (blockIdx.x == 0 && threadIdx.x == 0) ((gint*)counts)[2 * SAI2B_MAX_TASKS + (1 - parity)] = 0;  // and its count of non-idle robots
 	constexpr int GROUPS = 64 / otgg::G;
 #pragma unroll 1
 	for (int t = 0; t < P.n_tasks; t++) {

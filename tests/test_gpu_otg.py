@@ -300,6 +300,44 @@ def test_gpu_otg_idle_shortcut_still_sees_new_goals():
     assert np.abs(o.get_jt_desired(1)[0] - g.get_jt_desired(1)[0]).max() < 1e-12
 
 
+def test_generator_kernels_are_not_launched_while_every_generator_is_idle(monkeypatch):
+    """round 3: otg_kernel leaves the count of robots with a generator that is not idle; read back (every 8th tick,
+    asynchronously) as zero for a tick launched with the goals as they still are, it lets the host drop the two generator
+    launches from the tick — an idle generator's update neither reads nor writes anything — until a goal or a generator's
+    configuration is touched. Same torques as with SAI2B_NO_OTG_IDLE_SKIP=1, launch for launch fewer."""
+    B = 256
+    inp = pkg.workloads.make_inputs(3, B=B, seed=8)
+    o, g = _c3_pair(B)
+    monkeypatch.setenv("SAI2B_NO_OTG_IDLE_SKIP", "1")
+    _, h = _c3_pair(B)
+    monkeypatch.delenv("SAI2B_NO_OTG_IDLE_SKIP")
+    for c in (o, g, h):
+        c.set_state(inp["q"], inp["dq"])
+        c.reinitialize()
+
+    def per_tick(c, n=4):
+        l0 = c.counters()[0]
+        for _ in range(n):
+            c.tick()
+        return (c.counters()[0] - l0) / n
+
+    for _ in range(24):  # goals = current pose: idle after the first tick; the host has seen it by now
+        to, tg, th = o.tick(), g.tick(), h.tick()
+        g.synchronize()
+        assert np.array_equal(tg, th) and _err(tg, to).max() < TOL
+    assert per_tick(h) == 3 and per_tick(g) == 1  # counted launches: [the generators' two] + the tick's kernels as one
+    for _ in range(4):
+        o.tick()  # (the launch-count ticks above, for the oracle)
+    goal = inp["q"] + 0.04
+    for c in (o, g, h):
+        c.set_jt_goals(1, goal, None, None)
+    for _ in range(40):
+        to, tg, th = o.tick(), g.tick(), h.tick()
+        assert np.array_equal(tg, th) and _err(tg, to).max() < TOL
+    assert not g.get_otg_status(1)[0].any()
+    assert per_tick(g) == 3  # on their way: the generator kernels run
+
+
 def test_gpu_otg_reinitialize_mid_motion_ragged_batch():
     """reinitializeTasks() while the generators are moving (OTG objects re-initialised at the current
     pose, goals reset), a batch that fills neither a wavefront nor the planner's 8-lane groups, and two
